@@ -1,0 +1,452 @@
+/*
+ * gsss_oracle.c -- CPU ORACLE for the geodesic slice-sampler hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (geosss_amd/, include/) may link,
+ * import or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and there only as the checker / the CPU number printed beside
+ * the GPU number.
+ *
+ * It is a plain-C, double precision, one-chain-at-a-time restatement of the reference
+ * algorithm, function by function, each citing the reference file:line it follows
+ * (paths relative to /root/reference):
+ *
+ *   gor_radial_projection       geosss/sphere.py:10-18
+ *   gor_orthogonal_projection   geosss/sphere.py:21-26
+ *   gor_spherical_projection    geosss/sphere.py:29-33
+ *   gor_distance                geosss/sphere.py:64-68
+ *   gor_distance_slerp          geosss/spherical_curve.py:10-32
+ *   gor_find_nearest            geosss/spherical_curve.py:95-102
+ *   gor_logprob (vMF mixture)   geosss/distributions.py:156-157, 218-221
+ *   gor_logprob (Bingham)       geosss/distributions.py:78-86
+ *   gor_logprob (curve vMF)     geosss/distributions.py:272-275
+ *   gor_step (shrink)           geosss/mcmc.py:382-401
+ *   gor_step (reject)           geosss/mcmc.py:357-374
+ *   gor_run                     geosss/mcmc.py:55-77 (the sampling loop, many chains)
+ *
+ * Parity pin: the reference's own tests hold no golden vectors for this path
+ * (SURVEY.md §4); this oracle is pinned instead by the .npz files in tests/golden/, which
+ * tests/golden/make_golden.py produced by running the reference itself in the build
+ * container (tests/test_oracle_golden.py checks every one of them).
+ *
+ * Third-party pieces the reference calls on this path:
+ *   scipy.special.logsumexp (scipy 1.15.3)  -> gor_logsumexp restates its algorithm:
+ *       a_max + log(m) + log1p(sum_{a_i != a_max} exp(a_i - a_max) / m), m = #ties at max
+ *   scipy.special.i0                         -> NOT restated: log i0(kappa_k) is an
+ *       x-independent constant; the Python side passes it in (`lognorm`), computed with
+ *       scipy exactly as distributions.py:157 does.
+ *   numpy PCG64/ziggurat                     -> NOT restated: draws are either replayed from
+ *       a recorded stream (bit parity with the reference chain) or come from the
+ *       counter-based Philox4x32-10 stream specified in DESIGN.md "RNG stream", which the
+ *       HIP kernels implement identically (integer part bit-exact).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GOR_VMF_MIXTURE 1
+#define GOR_BINGHAM 2
+#define GOR_CURVE_VMF 3
+
+#define GOR_SHRINK 0
+#define GOR_REJECT 1
+
+#define GOR_ERR_MAX_TRIES 1
+#define GOR_ERR_NONFINITE 2
+#define GOR_ERR_REPLAY_EXHAUSTED 4
+
+typedef struct {
+    int32_t kind;
+    int32_t d;
+    int32_t k;             /* mixture components / curve knots */
+    const double *mu;      /* [k][d]  vMF: kappa_k * direction_k (distributions.py:126-127) */
+    const double *lognorm; /* [k]     log(2 pi) + log(i0(|mu_k|))   (distributions.py:157) */
+    const double *logw;    /* [k]     log of the normalised weights (distributions.py:213-220) */
+    const double *A;       /* [d][d]  Bingham precision (distributions.py:70) */
+    const double *knots;   /* [k][d]  SlerpCurve knots (spherical_curve.py:37,79) */
+    double kappa;          /* curve concentration (distributions.py:265) */
+} gor_target;
+
+/* ------------------------------------------------------------------ sphere.py */
+
+static double gor_dot(const double *a, const double *b, int d)
+{
+    double s = 0.0;
+    for (int i = 0; i < d; ++i) s += a[i] * b[i];
+    return s;
+}
+
+/* sphere.py:10-18 : x / (||x|| + 1e-100) */
+void gor_radial_projection(const double *x, int d, double *out)
+{
+    double nrm = sqrt(gor_dot(x, x, d)) + 1e-100;
+    for (int i = 0; i < d; ++i) out[i] = x[i] / nrm;
+}
+
+/* sphere.py:21-26 : x - (x . n) n  with n = radial_projection(y) */
+void gor_orthogonal_projection(const double *x, const double *y, int d, double *out)
+{
+    double *n = (double *)malloc(sizeof(double) * (size_t)d);
+    gor_radial_projection(y, d, n);
+    double c = gor_dot(x, n, d);
+    for (int i = 0; i < d; ++i) out[i] = x[i] - c * n[i];
+    free(n);
+}
+
+/* sphere.py:29-33 */
+void gor_spherical_projection(const double *x, const double *v, int d, double *out)
+{
+    double *t = (double *)malloc(sizeof(double) * (size_t)d);
+    gor_orthogonal_projection(x, v, d, t);
+    gor_radial_projection(t, d, out);
+    free(t);
+}
+
+static double gor_clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* sphere.py:64-68 */
+double gor_distance(const double *x, const double *y, int d)
+{
+    return acos(gor_clip(gor_dot(x, y, d), -1.0, 1.0));
+}
+
+/* ------------------------------------------------------------------ spherical_curve.py */
+
+/* spherical_curve.py:10-32 */
+double gor_distance_slerp(const double *x, const double *a, const double *b, int d, double *y)
+{
+    double theta = gor_distance(a, b, d);
+    double ax = gor_dot(a, x, d), bx = gor_dot(b, x, d);
+    double t = atan2(bx - ax * cos(theta), ax * sin(theta));
+    t = gor_clip(t, 0.0, theta);
+    double sa = sin(theta - t), sb = sin(t), den = sin(theta) + 1e-10;
+    for (int i = 0; i < d; ++i) y[i] = (sa * a[i] + sb * b[i]) / den;
+    return gor_distance(x, y, d);
+}
+
+/* spherical_curve.py:95-102 : first minimum wins (np.argmin) */
+void gor_find_nearest(const double *knots, int n_knots, int d, const double *x, double *out)
+{
+    double *y = (double *)malloc(sizeof(double) * (size_t)d);
+    double best = INFINITY;
+    int have = 0;
+    for (int s = 0; s + 1 < n_knots; ++s) {
+        double dist = gor_distance_slerp(x, knots + (size_t)s * d, knots + (size_t)(s + 1) * d, d, y);
+        if (!have || dist < best) {
+            best = dist;
+            have = 1;
+            memcpy(out, y, sizeof(double) * (size_t)d);
+        }
+    }
+    free(y);
+}
+
+/* ------------------------------------------------------------------ distributions.py */
+
+/* scipy 1.15.3 special.logsumexp restated (see header) */
+double gor_logsumexp(const double *a, int n)
+{
+    double amax = a[0];
+    for (int i = 1; i < n; ++i)
+        if (a[i] > amax) amax = a[i];
+    if (!isfinite(amax)) return amax; /* all -inf, or +inf / nan propagate */
+    int m = 0;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (a[i] == amax)
+            ++m;
+        else
+            s += exp(a[i] - amax);
+    }
+    return log1p(s / (double)m) + log((double)m) + amax;
+}
+
+double gor_logprob(const gor_target *t, const double *x)
+{
+    int d = t->d;
+    if (t->kind == GOR_VMF_MIXTURE) {
+        /* distributions.py:218-221 on top of :156-157 */
+        double *p = (double *)malloc(sizeof(double) * (size_t)t->k);
+        for (int k = 0; k < t->k; ++k) {
+            double lp = gor_dot(x, t->mu + (size_t)k * d, d) - t->lognorm[k];
+            p[k] = lp + t->logw[k];
+        }
+        double r = gor_logsumexp(p, t->k);
+        free(p);
+        return r;
+    }
+    if (t->kind == GOR_BINGHAM) {
+        /* distributions.py:84-86 : sum((x @ A) * x) */
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) {
+            double xa = 0.0;
+            for (int i = 0; i < d; ++i) xa += x[i] * t->A[(size_t)i * d + j];
+            s += xa * x[j];
+        }
+        return s;
+    }
+    if (t->kind == GOR_CURVE_VMF) {
+        /* distributions.py:272-275 */
+        double *y = (double *)malloc(sizeof(double) * (size_t)d);
+        gor_find_nearest(t->knots, t->k, d, x, y);
+        double r = t->kappa * gor_dot(x, y, d);
+        free(y);
+        return r;
+    }
+    return NAN;
+}
+
+void gor_logprob_batch(const gor_target *t, const double *X, int64_t n, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = gor_logprob(t, X + (size_t)i * t->d);
+}
+
+/* ------------------------------------------------------------------ RNG stream (DESIGN.md "RNG stream") */
+
+static void gor_philox_round(uint32_t c[4], const uint32_t k[2])
+{
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+void gor_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k[2] = {key[0], key[1]};
+    for (int r = 0; r < 10; ++r) {
+        gor_philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    memcpy(out, c, sizeof(c));
+}
+
+/* 53-bit uniform in [0,1) from two words, numpy's construction */
+static double gor_u53(uint32_t a, uint32_t b)
+{
+    return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+/* block `blk` of (seed, chain, step): two uniforms */
+void gor_stream_block(uint64_t seed, uint64_t chain, uint64_t step, uint32_t blk, double u[2])
+{
+    uint32_t ctr[4], key[2], w[4];
+    ctr[0] = blk;
+    ctr[1] = (uint32_t)step;
+    ctr[2] = (uint32_t)chain;
+    ctr[3] = (uint32_t)((chain >> 32) & 0xFFFFu) | ((uint32_t)((step >> 32) & 0xFFFFu) << 16);
+    key[0] = (uint32_t)seed;
+    key[1] = (uint32_t)(seed >> 32);
+    gor_philox4x32_10(ctr, key, w);
+    u[0] = gor_u53(w[0], w[1]);
+    u[1] = gor_u53(w[2], w[3]);
+}
+
+typedef struct {
+    /* replay */
+    const double *replay;
+    int64_t replay_len, cursor;
+    int exhausted;
+    /* philox */
+    uint64_t seed, chain, step;
+    int d;
+    int64_t try_idx;
+    double cached;
+} gor_draws;
+
+static double gor_take(gor_draws *g)
+{
+    if (g->cursor >= g->replay_len) {
+        g->exhausted = 1;
+        return 0.5;
+    }
+    return g->replay[g->cursor++];
+}
+
+/* the d standard normals of a step (mcmc.py:387) */
+static void gor_draw_normals(gor_draws *g, double *z)
+{
+    int d = g->d;
+    if (g->replay) {
+        for (int i = 0; i < d; ++i) z[i] = gor_take(g);
+        return;
+    }
+    for (int j = 0; 2 * j < d; ++j) {
+        double u[2];
+        gor_stream_block(g->seed, g->chain, g->step, (uint32_t)(1 + j), u);
+        double r = sqrt(-2.0 * log(1.0 - u[0]));
+        double ang = 6.283185307179586 * u[1];
+        z[2 * j] = r * cos(ang);
+        if (2 * j + 1 < d) z[2 * j + 1] = r * sin(ang);
+    }
+}
+
+/* the threshold uniform (mcmc.py:389) and theta0 uniform (mcmc.py:391) */
+static void gor_draw_step_uniforms(gor_draws *g, double *u_thr, double *u_theta0, int need_theta0)
+{
+    if (g->replay) {
+        *u_thr = gor_take(g);
+        *u_theta0 = need_theta0 ? gor_take(g) : 0.0;
+        return;
+    }
+    double u[2];
+    gor_stream_block(g->seed, g->chain, g->step, 0u, u);
+    *u_thr = u[0];
+    *u_theta0 = u[1];
+}
+
+/* the uniform of try number `g->try_idx` (mcmc.py:395) */
+static double gor_draw_try(gor_draws *g)
+{
+    if (g->replay) return gor_take(g);
+    int64_t t = g->try_idx++;
+    if (t & 1) return g->cached;
+    double u[2];
+    uint32_t nb = (uint32_t)((g->d + 1) / 2);
+    gor_stream_block(g->seed, g->chain, g->step, 1u + nb + (uint32_t)(t >> 1), u);
+    g->cached = u[1];
+    return u[0];
+}
+
+/* ------------------------------------------------------------------ mcmc.py */
+
+/* one transition.  Returns the error bits; *tries = number of log_prob(y) evaluations. */
+static int gor_step(const gor_target *t, double *x, gor_draws *g, int sampler, int64_t max_tries, int64_t *tries,
+                    double *trace_thr, double *scratch)
+{
+    int d = t->d;
+    double *z = scratch, *u = scratch + d, *y = scratch + 2 * d;
+    const double two_pi = 2.0 * 3.141592653589793; /* 2 * np.pi */
+
+    g->try_idx = 0;
+    gor_draw_normals(g, z);                /* mcmc.py:387 */
+    gor_spherical_projection(z, x, d, u);  /* mcmc.py:387 */
+    double u_thr, u_th0;
+    gor_draw_step_uniforms(g, &u_thr, &u_th0, sampler == GOR_SHRINK);
+    double px = gor_logprob(t, x);
+    double threshold = px + log(u_thr);    /* mcmc.py:389 */
+    if (trace_thr) *trace_thr = threshold;
+    if (!(px > -INFINITY) || isnan(px)) {
+        *tries = 0;
+        return GOR_ERR_NONFINITE;
+    }
+    double lo, hi;
+    if (sampler == GOR_SHRINK) {
+        double theta0 = 0.0 + (two_pi - 0.0) * u_th0; /* mcmc.py:391 */
+        lo = theta0 - two_pi;                            /* mcmc.py:392 */
+        hi = theta0;
+    } else {
+        lo = 0.0;                                        /* mcmc.py:367 */
+        hi = two_pi;
+    }
+    int64_t n = 0;
+    for (;;) {
+        if (n >= max_tries) {
+            *tries = n;
+            return GOR_ERR_MAX_TRIES;
+        }
+        double theta = lo + (hi - lo) * gor_draw_try(g); /* mcmc.py:395 */
+        double c = cos(theta), s = sin(theta);
+        for (int i = 0; i < d; ++i) y[i] = c * x[i] + s * u[i]; /* mcmc.py:396 */
+        ++n;
+        if (gor_logprob(t, y) > threshold) {             /* mcmc.py:397 */
+            memcpy(x, y, sizeof(double) * (size_t)d);
+            *tries = n;
+            return g->exhausted ? GOR_ERR_REPLAY_EXHAUSTED : 0;
+        }
+        if (sampler == GOR_SHRINK) {                     /* mcmc.py:400 */
+            if (theta < 0.0)
+                lo = theta;
+            else
+                hi = theta;
+        }
+        if (g->exhausted) {
+            *tries = n;
+            return GOR_ERR_REPLAY_EXHAUSTED;
+        }
+    }
+}
+
+/*
+ * Advance n_chains independent chains by n_steps transitions each.
+ *   state      [n_chains][d] in/out (row per chain)
+ *   samples    [n_chains][n_keep][d] or NULL; a state is kept after every `thin`-th step
+ *   n_reject, n_tries [n_chains] are ADDED to; err [n_chains] is OR-ed into
+ *   replay     [n_chains][replay_stride] recorded draws in consumption order, or NULL
+ *   thr_trace  [n_chains][n_steps] or NULL
+ * chain ids are chain_offset + i, step ids step_offset + s (the RNG counter), so any
+ * partition of chains / steps over calls or devices gives the same numbers.
+ */
+int gor_run(const gor_target *t, double *state, int64_t n_chains, int64_t n_steps, int64_t thin, uint64_t seed,
+            uint64_t chain_offset, uint64_t step_offset, int sampler, int64_t max_tries, double *samples,
+            int64_t *n_reject, int64_t *n_tries, int32_t *err, const double *replay, int64_t replay_stride,
+            double *thr_trace, int n_threads)
+{
+    int d = t->d;
+    if (thin < 1) thin = 1;
+    int64_t n_keep = n_steps / thin;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (int64_t c = 0; c < n_chains; ++c) {
+        double *scratch = (double *)malloc(sizeof(double) * (size_t)(3 * d));
+        double *x = state + (size_t)c * d;
+        gor_draws g;
+        memset(&g, 0, sizeof(g));
+        g.d = d;
+        g.seed = seed;
+        g.chain = chain_offset + (uint64_t)c;
+        if (replay) {
+            g.replay = replay + (size_t)c * replay_stride;
+            g.replay_len = replay_stride;
+        }
+        for (int64_t s = 0; s < n_steps; ++s) {
+            g.step = step_offset + (uint64_t)s;
+            int64_t tries = 0;
+            int e = gor_step(t, x, &g, sampler, max_tries, &tries, thr_trace ? thr_trace + c * n_steps + s : NULL,
+                             scratch);
+            if (n_tries) n_tries[c] += tries;
+            if (n_reject) n_reject[c] += e ? tries : tries - 1;
+            if (err && e) err[c] |= e;
+            if (samples && (s + 1) % thin == 0) {
+                int64_t row = (s + 1) / thin - 1;
+                memcpy(samples + ((size_t)c * n_keep + row) * d, x, sizeof(double) * (size_t)d);
+            }
+            if (e) break;
+        }
+        free(scratch);
+    }
+    return 0;
+}
+
+/* initial states: the device twin of sphere.sample_sphere (sphere.py:39-50) draws its
+ * normals from stream blocks of step id 2^48-1 (reserved), see DESIGN.md */
+void gor_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int d, double *out)
+{
+    gor_draws g;
+    for (int64_t c = 0; c < n; ++c) {
+        memset(&g, 0, sizeof(g));
+        g.d = d;
+        g.seed = seed;
+        g.chain = chain_offset + (uint64_t)c;
+        g.step = 0xFFFFFFFFFFFFull;
+        double *z = out + (size_t)c * d;
+        gor_draw_normals(&g, z);
+        gor_radial_projection(z, d, z);
+    }
+}
+
+int gor_has_openmp(void)
+{
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -1,0 +1,206 @@
+"""ctypes front-end of the CPU oracle (oracle/gsss_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (geosss_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+from scipy.special import i0, ive
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libgsss_oracle.so")
+
+VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
+SHRINK, REJECT = 0, 1
+ERR_MAX_TRIES, ERR_NONFINITE, ERR_REPLAY_EXHAUSTED = 1, 2, 4
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "gsss_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+class _Target(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("k", C.c_int32),
+                ("mu", C.c_void_p), ("lognorm", C.c_void_p), ("logw", C.c_void_p),
+                ("A", C.c_void_p), ("knots", C.c_void_p), ("kappa", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.gor_logprob.restype = C.c_double
+        _lib.gor_distance_slerp.restype = C.c_double
+        _lib.gor_distance.restype = C.c_double
+        _lib.gor_logsumexp.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def log_i0(kappa):
+    """log(i0(kappa)) exactly as geosss/distributions.py:157 evaluates it (overflows to inf
+    at kappa >~ 713.99, which the reference inherits)."""
+    with np.errstate(over="ignore"):
+        return np.log(i0(kappa))
+
+
+class Target:
+    """Plain-array description of a target + the C struct the oracle reads."""
+
+    def __init__(self, kind, d, k=0, mu=None, lognorm=None, logw=None, A=None, knots=None, kappa=0.0):
+        self.kind, self.d, self.k = kind, int(d), int(k)
+        self.mu = _f64(mu) if mu is not None else None
+        self.lognorm = _f64(lognorm) if lognorm is not None else None
+        self.logw = _f64(logw) if logw is not None else None
+        self.A = _f64(A) if A is not None else None
+        self.knots = _f64(knots) if knots is not None else None
+        self.kappa = float(kappa)
+        self.c = _Target(kind, self.d, self.k, _p(self.mu), _p(self.lognorm), _p(self.logw), _p(self.A),
+                         _p(self.knots), self.kappa)
+
+    @classmethod
+    def vmf_mixture(cls, mu, weights=None):
+        mu = _f64(mu)
+        k, d = mu.shape
+        w = np.ones(k) if weights is None else np.array(weights, dtype=float)
+        w = w / w.sum()                                            # distributions.py:213-216
+        lognorm = np.log(2 * np.pi) + log_i0(np.linalg.norm(mu, axis=1))  # distributions.py:157
+        return cls(VMF_MIXTURE, d, k, mu=mu, lognorm=lognorm, logw=np.log(w))
+
+    @classmethod
+    def bingham(cls, A):
+        A = _f64(A)
+        return cls(BINGHAM, A.shape[0], A=A)
+
+    @classmethod
+    def curve_vmf(cls, knots, kappa):
+        knots = _f64(knots)
+        return cls(CURVE_VMF, knots.shape[1], knots.shape[0], knots=knots, kappa=kappa)
+
+    @classmethod
+    def from_fixture(cls, z, prefix="target_"):
+        kind = str(z[prefix + "kind"])
+        if kind == "vmf_mixture":
+            return cls.vmf_mixture(z[prefix + "mu"], z[prefix + "weights"])
+        if kind == "bingham":
+            return cls.bingham(z[prefix + "A"])
+        if kind == "curve_vmf":
+            return cls.curve_vmf(z[prefix + "knots"], float(z[prefix + "kappa"]))
+        raise ValueError(kind)
+
+    def log_prob(self, X):
+        X = _f64(X)
+        if X.ndim == 1:
+            return float(lib().gor_logprob(C.byref(self.c), _p(X)))
+        out = np.empty(len(X))
+        lib().gor_logprob_batch(C.byref(self.c), _p(X), C.c_int64(len(X)), _p(out))
+        return out
+
+
+def run(target, state, n_steps, seed=0, chain_offset=0, step_offset=0, sampler=SHRINK, thin=1, max_tries=100000,
+        keep_samples=True, replay=None, trace_threshold=False, n_threads=1):
+    """Advance every row of `state` (n_chains, d) by n_steps transitions.
+
+    Returns dict(state, samples (n_chains, n_keep, d) | None, n_reject, n_tries, err, threshold).
+    """
+    state = np.array(state, dtype=np.float64, order="C", copy=True)
+    single = state.ndim == 1
+    if single:
+        state = state[None]
+    n, d = state.shape
+    assert d == target.d
+    n_keep = n_steps // thin
+    samples = np.empty((n, n_keep, d)) if keep_samples else None
+    n_reject = np.zeros(n, dtype=np.int64)
+    n_tries = np.zeros(n, dtype=np.int64)
+    err = np.zeros(n, dtype=np.int32)
+    thr = np.full((n, n_steps), np.nan) if trace_threshold else None
+    stride = 0
+    if replay is not None:
+        replay = _f64(replay)
+        if replay.ndim == 1:
+            replay = replay[None]
+        assert replay.shape[0] == n
+        stride = replay.shape[1]
+    lib().gor_run(C.byref(target.c), _p(state), C.c_int64(n), C.c_int64(n_steps), C.c_int64(thin),
+                  C.c_uint64(seed), C.c_uint64(chain_offset), C.c_uint64(step_offset), C.c_int(sampler),
+                  C.c_int64(max_tries), _p(samples), _p(n_reject), _p(n_tries), _p(err), _p(replay),
+                  C.c_int64(stride), _p(thr), C.c_int(n_threads))
+    return dict(state=state[0] if single else state, samples=samples, n_reject=n_reject, n_tries=n_tries, err=err,
+                threshold=thr)
+
+
+def sample_sphere(seed, n, d, chain_offset=0):
+    out = np.empty((n, d))
+    lib().gor_sample_sphere(C.c_uint64(seed), C.c_uint64(chain_offset), C.c_int64(n), C.c_int(d), _p(out))
+    return out
+
+
+def stream_block(seed, chain, step, blk):
+    u = np.empty(2)
+    lib().gor_stream_block(C.c_uint64(seed), C.c_uint64(chain), C.c_uint64(step), C.c_uint32(blk), _p(u))
+    return u
+
+
+def philox4x32_10(ctr, key):
+    ctr = np.asarray(ctr, dtype=np.uint32)
+    key = np.asarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    lib().gor_philox4x32_10(_p(ctr), _p(key), _p(out))
+    return out
+
+
+def radial_projection(x):
+    x = _f64(x)
+    out = np.empty_like(x)
+    lib().gor_radial_projection(_p(x), C.c_int(len(x)), _p(out))
+    return out
+
+
+def orthogonal_projection(x, y):
+    x, y = _f64(x), _f64(y)
+    out = np.empty_like(x)
+    lib().gor_orthogonal_projection(_p(x), _p(y), C.c_int(len(x)), _p(out))
+    return out
+
+
+def spherical_projection(x, v):
+    x, v = _f64(x), _f64(v)
+    out = np.empty_like(x)
+    lib().gor_spherical_projection(_p(x), _p(v), C.c_int(len(x)), _p(out))
+    return out
+
+
+def distance_slerp(x, a, b):
+    x, a, b = _f64(x), _f64(a), _f64(b)
+    y = np.empty_like(x)
+    dist = lib().gor_distance_slerp(_p(x), _p(a), _p(b), C.c_int(len(x)), _p(y))
+    return dist, y
+
+
+def find_nearest(knots, x):
+    knots, x = _f64(knots), _f64(x)
+    out = np.empty_like(x)
+    lib().gor_find_nearest(_p(knots), C.c_int(knots.shape[0]), C.c_int(knots.shape[1]), _p(x), _p(out))
+    return out
+
+
+def logsumexp(a):
+    a = _f64(a)
+    return float(lib().gor_logsumexp(_p(a), C.c_int(len(a))))

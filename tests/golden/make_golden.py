@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box and the
+test-suite only ever read the emitted .npz files.  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+What is recorded:
+
+* traj_<case>.npz   one chain of the reference ShrinkageSphericalSliceSampler /
+                    RejectionSphericalSliceSampler (geosss/mcmc.py:335-401) with every
+                    RNG draw captured in consumption order, the state after every step,
+                    the per-step threshold, the number of tries per step, the log-density
+                    of every proposal, and the smallest |p(y)-threshold| margin.
+* logprob_kat.npz   pdf.log_prob known-answer tables (1-D and 2-D call) per target.
+* geometry_kat.npz  sphere.radial/orthogonal/spherical_projection, distance_slerp,
+                    SlerpCurve.find_nearest on random (also non-unit) inputs.
+* stats_<case>.npz  statistical pins from several independent reference chains
+                    (rejections/step, mode occupancy, mean geodesic step, moments).
+
+The RNG proxy: `uniform(lo, hi)` is answered as `lo + (hi-lo)*random()`, which is
+bitwise what numpy's Generator.uniform does; the generator asserts that the proxied chain
+equals the unpatched chain bit for bit before writing anything.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+import geosss as gs  # noqa: E402
+from geosss import sphere as rsphere  # noqa: E402
+from geosss.distributions import CurvedVonMisesFisher  # noqa: E402
+from geosss.spherical_curve import SlerpCurve, brownian_curve, distance_slerp  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class RecordingRNG:
+    """Stands in for sampler.rng; logs every double the sampler consumes."""
+
+    def __init__(self, seed):
+        self.g = np.random.default_rng(seed)
+        self.draws = []
+
+    def standard_normal(self, n):
+        z = self.g.standard_normal(n)
+        self.draws.extend(z.tolist())
+        return z
+
+    def random(self):
+        u = self.g.random()
+        self.draws.append(u)
+        return u
+
+    def uniform(self, lo, hi):
+        u = self.g.random()
+        self.draws.append(u)
+        return lo + (hi - lo) * u
+
+
+class LoggingTarget:
+    """Wraps pdf.log_prob so every evaluation made by the sampler is logged."""
+
+    def __init__(self, pdf):
+        self.pdf = pdf
+        self.vals = []
+
+    def log_prob(self, x):
+        v = self.pdf.log_prob(x)
+        self.vals.append(float(v))
+        return v
+
+
+def record_trajectory(cls, pdf, x0, seed, n_steps):
+    # unpatched chain (truth)
+    s0 = cls(pdf, np.array(x0, dtype=float), seed)
+    truth = [np.array(s0.state)]
+    for _ in range(n_steps):
+        truth.append(np.copy(next(s0)))
+    truth = np.array(truth)
+
+    # proxied chain
+    tgt = LoggingTarget(pdf)
+    s = cls(tgt, np.array(x0, dtype=float), seed)
+    s.rng = RecordingRNG(seed)
+    states = [np.array(s.state)]
+    step_draw_offset = [0]
+    tries = []
+    thr = []
+    logp_state = []
+    prop_logp = []
+    prop_offset = [0]
+    d = len(x0)
+    for _ in range(n_steps):
+        nv0 = len(tgt.vals)
+        nd0 = len(s.rng.draws)
+        y = next(s)
+        states.append(np.copy(y))
+        vals = tgt.vals[nv0:]
+        draws = s.rng.draws[nd0:]
+        # order of draws in a step: d normals, U(threshold), then the thetas
+        u_thr = draws[d]
+        logp_state.append(vals[0])
+        thr.append(vals[0] + np.log(u_thr))
+        tries.append(len(vals) - 1)
+        prop_logp.extend(vals[1:])
+        prop_offset.append(len(prop_logp))
+        step_draw_offset.append(len(s.rng.draws))
+    states = np.array(states)
+    assert np.array_equal(states, truth), "proxy RNG changed the chain"
+    prop_logp = np.array(prop_logp)
+    thr = np.array(thr)
+    margin = np.inf
+    for i in range(n_steps):
+        seg = prop_logp[prop_offset[i]:prop_offset[i + 1]]
+        margin = min(margin, np.min(np.abs(seg - thr[i])))
+    return dict(
+        states=states,
+        draws=np.array(s.rng.draws),
+        step_draw_offset=np.array(step_draw_offset, dtype=np.int64),
+        tries=np.array(tries, dtype=np.int64),
+        threshold=thr,
+        logp_state=np.array(logp_state),
+        prop_logp=prop_logp,
+        prop_offset=np.array(prop_offset, dtype=np.int64),
+        n_reject=np.int64(s.n_reject),
+        min_margin=np.float64(margin),
+        seed=np.int64(seed),
+    )
+
+
+# ----------------------------------------------------------------------------- targets
+
+
+def target_params(pdf):
+    """Flatten a reference pdf into the plain arrays our C-ABI takes."""
+    if isinstance(pdf, gs.MixtureModel):
+        mu = np.array([p.mu for p in pdf.pdfs])
+        return dict(kind="vmf_mixture", mu=mu, weights=np.array(pdf.weights))
+    if isinstance(pdf, gs.Bingham):
+        return dict(kind="bingham", A=np.array(pdf.A))
+    if isinstance(pdf, CurvedVonMisesFisher):
+        return dict(kind="curve_vmf", knots=np.array(pdf.curve.knots), kappa=np.float64(pdf.kappa))
+    raise TypeError(pdf)
+
+
+def readme_mixture():
+    mus = np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
+    return gs.MixtureModel([gs.VonMisesFisher(80.0 * mu) for mu in mus])
+
+
+def mixture(d, K, kappa, weights=None):
+    modes = gs.sphere.sample_sphere(d - 1, K, seed=1234)  # scripts/mixture_vMF.py:406-411
+    return gs.MixtureModel([gs.VonMisesFisher(kappa * mu) for mu in modes], weights)
+
+
+def curve_target(d, kappa):
+    knots = brownian_curve(n_points=10, dimension=d, step_size=0.5, seed=4562)  # scripts/curve_vMF.py:577-589
+    return CurvedVonMisesFisher(SlerpCurve(knots), kappa)
+
+
+def cases():
+    out = {}
+    out["vmfmix_readme"] = (readme_mixture(), np.array([-0.86, 0.19, -0.47]), 3521, 1099)
+    out["vmfmix_k10_kappa500"] = (mixture(3, 10, 500.0), gs.sphere.sample_sphere(2, seed=1345), 77, 400)
+    out["vmfmix_d10_k5_kappa100"] = (mixture(10, 5, 100.0), gs.sphere.sample_sphere(9, seed=1345), 78, 300)
+    out["vmfmix_d4_k4_weighted"] = (
+        mixture(4, 4, 30.0, weights=[1.0, 2.0, 3.0, 0.5]), gs.sphere.sample_sphere(3, seed=5), 79, 300)
+    b10 = gs.random_bingham(d=10, vmax=30.0, vmin=0.0, eigensystem=True, seed=6982)  # scripts/bingham.py:131
+    out["bingham_d10_vmax30"] = (b10, np.array(b10.mode), 80, 400)
+    b5 = gs.random_bingham(d=5, vmax=20.0, vmin=-3.0, eigensystem=False, seed=11)
+    out["bingham_d5_dense"] = (b5, gs.sphere.sample_sphere(4, seed=6), 81, 300)
+    b50 = gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=True, seed=6982)
+    out["bingham_d50_vmax300"] = (b50, np.array(b50.mode), 82, 150)
+    for d, kappa, n in ((3, 300.0, 300), (10, 800.0, 300), (10, 500.0, 200), (24, 800.0, 150),
+                        (50, 800.0, 150), (200, 800.0, 100)):
+        out[f"curve_d{d}_kappa{int(kappa)}"] = (
+            curve_target(d, kappa), gs.sphere.sample_sphere(d - 1, seed=1345), 90 + d, n)
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def flat_params(p):
+    return {f"target_{k}": (np.array(v) if not isinstance(v, str) else np.array(v)) for k, v in p.items()}
+
+
+def make_trajectories():
+    for name, (pdf, x0, seed, n) in cases().items():
+        t0 = time.time()
+        rec = record_trajectory(gs.ShrinkageSphericalSliceSampler, pdf, x0, seed, n)
+        print(f"{name}: {n} steps, rej/step={rec['n_reject'] / n:.3f}, "
+              f"min margin={rec['min_margin']:.3e}, {time.time() - t0:.1f}s")
+        save(f"traj_{name}.npz", x0=np.array(x0), sampler=np.array("shrink"), **flat_params(target_params(pdf)), **rec)
+    # rejection sampler (mcmc.py:357-374): README target and the small Bingham
+    for name, n in (("vmfmix_readme", 60), ("bingham_d10_vmax30", 150)):
+        pdf, x0, seed, _ = cases()[name]
+        rec = record_trajectory(gs.RejectionSphericalSliceSampler, pdf, x0, seed, n)
+        print(f"reject_{name}: {n} steps, rej/step={rec['n_reject'] / n:.3f}, min margin={rec['min_margin']:.3e}")
+        save(f"traj_reject_{name}.npz", x0=np.array(x0), sampler=np.array("reject"),
+             **flat_params(target_params(pdf)), **rec)
+
+    # The README call itself: cls(pdf, init, seed).sample(1000, 100)  (README.md:44-64)
+    pdf = readme_mixture()
+    pdf.log_prob.reset_counters()
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.array([-0.86, 0.19, -0.47]), 3521)
+    samples = s.sample(1000, 100)
+    save("readme_sample_call.npz", samples=samples, n_reject=np.int64(s.n_reject),
+         num_calls=np.int64(pdf.log_prob.num_calls))
+
+
+def make_logprob_kat():
+    rng = np.random.default_rng(20260101)
+    arrays = {}
+    for name, (pdf, x0, _, _) in cases().items():
+        d = len(x0)
+        X = rsphere.radial_projection(rng.standard_normal((256, d)))
+        X[200:] *= rng.uniform(0.5, 1.5, size=(56, 1))  # non-unit rows: the chain state is never renormalised
+        lp2 = np.asarray(pdf.log_prob(X), dtype=float)
+        lp1 = np.array([float(pdf.log_prob(x)) for x in X])
+        assert np.allclose(lp1, lp2, rtol=0, atol=1e-9)
+        arrays[f"{name}__X"] = X
+        arrays[f"{name}__logp"] = lp1
+        arrays[f"{name}__logp_batched"] = lp2
+        for k, v in flat_params(target_params(pdf)).items():
+            arrays[f"{name}__{k}"] = v
+    save("logprob_kat.npz", **arrays)
+
+
+def make_geometry_kat():
+    rng = np.random.default_rng(424242)
+    arrays = {}
+    for d in (3, 10, 50):
+        X = rng.standard_normal((64, d))  # pole, not unit
+        Z = rng.standard_normal((64, d))
+        arrays[f"d{d}_x"] = X
+        arrays[f"d{d}_z"] = Z
+        arrays[f"d{d}_radial"] = np.array([rsphere.radial_projection(x) for x in X])
+        arrays[f"d{d}_ortho"] = np.array([rsphere.orthogonal_projection(z, x) for z, x in zip(Z, X)])
+        arrays[f"d{d}_spherical"] = np.array([rsphere.spherical_projection(z, x) for z, x in zip(Z, X)])
+        # slerp distance incl. clip edges: a few queries beyond either end of the arc
+        a = rsphere.radial_projection(rng.standard_normal((64, d)))
+        b = rsphere.radial_projection(a + 0.6 * rng.standard_normal((64, d)))
+        q = rsphere.radial_projection(rng.standard_normal((64, d)))
+        q[:16] = rsphere.radial_projection(a[:16] + 0.3 * (a[:16] - b[:16]))   # t < 0 side
+        q[16:32] = rsphere.radial_projection(b[16:32] + 0.3 * (b[16:32] - a[16:32]))  # t > theta side
+        q[32:40] = rsphere.radial_projection(0.4 * a[32:40] + 0.6 * b[32:40])  # on the arc
+        dist, near = zip(*[distance_slerp(x, aa, bb) for x, aa, bb in zip(q, a, b)])
+        arrays[f"d{d}_slerp_a"] = a
+        arrays[f"d{d}_slerp_b"] = b
+        arrays[f"d{d}_slerp_q"] = q
+        arrays[f"d{d}_slerp_dist"] = np.array(dist)
+        arrays[f"d{d}_slerp_near"] = np.array(near)
+        knots = brownian_curve(n_points=10, dimension=d, step_size=0.5, seed=4562)
+        curve = SlerpCurve(knots)
+        arrays[f"d{d}_knots"] = knots
+        arrays[f"d{d}_nearest"] = np.array([curve.find_nearest(x) for x in q])
+    save("geometry_kat.npz", **arrays)
+
+
+def _stat_chain(args):
+    name, seed_state, n_steps, burn = args
+    pdf, x0, _, _ = cases()[name]
+    ss = np.random.SeedSequence(entropy=seed_state[0], spawn_key=seed_state[1])
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.array(x0), ss)
+    X = s.sample(n_steps + burn, burnin=0)
+    rej_total = s.n_reject
+    X = X[burn:]
+    geo = np.arccos(np.clip(np.sum(X[1:] * X[:-1], axis=-1), -1, 1))
+    out = dict(mean=X.mean(0), second=(X[:, :, None] * X[:, None, :]).mean(0), rej_per_step=rej_total / (n_steps + burn - 1),
+               geo_step=geo.mean(), logp_mean=np.mean(pdf.log_prob(X)) if name.startswith(("vmf", "bing")) else np.nan)
+    if name.startswith("vmfmix"):
+        modes = np.array([p.mu / np.linalg.norm(p.mu) for p in pdf.pdfs])
+        occ = np.bincount(np.argmax(X @ modes.T, axis=1), minlength=len(modes)) / len(X)
+        out["occupancy"] = occ
+    return out
+
+
+def make_stats():
+    from concurrent.futures import ProcessPoolExecutor
+
+    plan = {"vmfmix_readme": 12000, "vmfmix_k10_kappa500": 8000, "bingham_d10_vmax30": 60000,
+            "curve_d10_kappa800": 4000}
+    for name, n_steps in plan.items():
+        t0 = time.time()
+        seeds = np.random.SeedSequence(48385).spawn(8)  # scripts/bingham.py:87-88 pattern
+        jobs = [(name, (s.entropy, s.spawn_key), n_steps, n_steps // 10) for s in seeds]
+        with ProcessPoolExecutor(8) as ex:
+            res = list(ex.map(_stat_chain, jobs))
+        arrays = {k: np.array([r[k] for r in res]) for k in res[0]}
+        arrays["n_steps"] = np.int64(n_steps)
+        arrays["n_chains"] = np.int64(len(res))
+        print(f"stats {name}: rej/step={arrays['rej_per_step'].mean():.3f} geo={arrays['geo_step'].mean():.3f} "
+              f"({time.time() - t0:.0f}s)")
+        save(f"stats_{name}.npz", **arrays)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats"]
+    if "traj" in what:
+        make_trajectories()
+    if "logprob" in what:
+        make_logprob_kat()
+    if "geometry" in what:
+        make_geometry_kat()
+    if "stats" in what:
+        make_stats()
