@@ -1,0 +1,19 @@
+"""geosss_amd -- many-chain geodesic slice sampling on the sphere for AMD MI355X (gfx950).
+
+Drop-in for the slice-sampler path of microscopic-image-analysis/geosss:
+
+    import geosss_amd as gs
+    pdf = gs.MixtureModel([gs.VonMisesFisher(80.0 * mu) for mu in mus])
+    samples = gs.ShrinkageSphericalSliceSampler(pdf, init_state, seed).sample(n_samples, burnin)
+"""
+from . import _lib, sphere
+from .distributions import (Bingham, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
+                            brownian_curve, random_bingham)
+from .mcmc import RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, determine_burnin
+from .sphere import sample_sphere, sample_sphere_device
+from .utils import SamplerLauncher, count_calls, counter
+
+__all__ = ["Bingham", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
+           "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
+           "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
+           "sphere"]

@@ -1,0 +1,81 @@
+"""Builds geosss_amd/libgsss_hip.so (the C-ABI + HIP kernels) with hipcc for gfx950.
+
+    python -m geosss_amd.build [--force] [--jobs N]
+
+One object per .hip translation unit (compiled in parallel), linked into a single shared
+library that lives IN-TREE next to this file so that it travels with the repository snapshot.
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libgsss_hip.so")
+ARCH = "gfx950"
+
+CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+            "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "gsss.h"))
+    hs.append(os.path.abspath(__file__))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def compile_one(src, force, extra):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), headers_mtime()):
+        return obj, False
+    cmd = [hipcc(), *CXXFLAGS, *extra, "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, jobs=None, extra=(), verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    jobs = jobs or min(len(srcs), os.cpu_count() or 1)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        res = list(ex.map(lambda s: compile_one(s, force, list(extra)), srcs))
+    objs = [o for o, _ in res]
+    if any(changed for _, changed in res) or not os.path.exists(LIB):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        subprocess.check_call(cmd)
+        if verbose:
+            print(f"linked {LIB}")
+    elif verbose:
+        print(f"{LIB} is up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--resource-usage", action="store_true", help="print per-kernel VGPR/SGPR/LDS usage")
+    a = ap.parse_args()
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if a.resource_usage else []
+    build(force=a.force or a.resource_usage, jobs=a.jobs, extra=extra)

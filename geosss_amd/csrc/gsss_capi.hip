@@ -1,0 +1,471 @@
+// gsss_capi.hip -- the extern "C" surface declared in include/gsss.h, plus the layout and
+// initial-state kernels.  No torch types, no exceptions across the boundary.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gsss_launch.h"
+
+namespace gsss {
+
+// ------------------------------------------------------------------------------------------
+// error text (thread local)
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// vector layout table / selection
+// ------------------------------------------------------------------------------------------
+static const VecInfo kVecs[] = {
+#define GSSS_VEC_ROW(ID, V, NAME) {ID, V::L, V::N, V::DPAD, V::kExactDim, NAME},
+    GSSS_VEC_LIST(GSSS_VEC_ROW)
+#undef GSSS_VEC_ROW
+};
+
+const VecInfo *vec_table(int *count)
+{
+    *count = (int)(sizeof(kVecs) / sizeof(kVecs[0]));
+    return kVecs;
+}
+
+int select_vec(int d, int variant)
+{
+    int n;
+    const VecInfo *v = vec_table(&n);
+    if (variant != 0) {
+        for (int i = 0; i < n; ++i)
+            if (v[i].id == variant) {
+                if (v[i].exact_dim ? v[i].dpad == d : d <= v[i].dpad) return variant;
+                set_error("kernel variant %s does not cover d=%d", v[i].name, d);
+                return GSSS_E_UNSUPPORTED;
+            }
+        set_error("unknown kernel variant %d", variant);
+        return GSSS_E_INVALID;
+    }
+    for (int i = 0; i < n; ++i)  // lane layouts first (exact d), then the smallest cooperative one
+        if (v[i].exact_dim && v[i].dpad == d) return v[i].id;
+    for (int i = 0; i < n; ++i)
+        if (!v[i].exact_dim && d <= v[i].dpad) return v[i].id;
+    set_error("no kernel variant covers d=%d (max %d)", d, v[n - 1].dpad);
+    return GSSS_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------
+// device guard: HIP's current device is per host thread; leave it as we found it
+// ------------------------------------------------------------------------------------------
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+        if (!ok) set_error("hipSetDevice(%d) failed", device);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// layout kernels: out[c][r] = in[r][c] for a row-major [R][C] matrix of doubles, LDS tiled so
+// that both the read and the write are 64-lane coalesced (HBM-bound; 16 B of traffic per element)
+// ------------------------------------------------------------------------------------------
+constexpr int kTile = 64;
+
+__global__ void __launch_bounds__(kBlock) transpose_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                           int64_t R, int64_t C)
+{
+    __shared__ double tile[kTile][kTile + 1];
+    const int64_t gx = (C + kTile - 1) / kTile;
+    const int64_t r0 = ((int64_t)blockIdx.x / gx) * kTile, c0 = ((int64_t)blockIdx.x % gx) * kTile;
+    const int tx = threadIdx.x % kTile, ty = threadIdx.x / kTile;  // 64 x 4
+    for (int i = ty; i < kTile; i += kBlock / kTile) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        if (r < R && c < C) tile[i][tx] = in[r * C + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < kTile; i += kBlock / kTile) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) out[c * R + r] = tile[tx][i];
+    }
+}
+
+static int transpose(const double *in, double *out, int64_t R, int64_t C, int device, hipStream_t st)
+{
+    if (R <= 0 || C <= 0) return GSSS_OK;
+    if (!in || !out) {
+        set_error("null buffer");
+        return GSSS_E_INVALID;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    const int64_t gx = (C + kTile - 1) / kTile, gy = (R + kTile - 1) / kTile;
+    if (gx * gy > 0x7FFFFFFFll) {
+        set_error("transpose: %lld x %lld exceeds the grid", (long long)R, (long long)C);
+        return GSSS_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(gx * gy)), dim3(kBlock), 0, st, in, out, R, C);
+    GSSS_HIP_TRY(hipGetLastError());
+    return GSSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sphere.sample_sphere twin: normals from the reserved step id, radially projected
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, uint64_t chain_offset, int64_t n, int d,
+                                                               double *__restrict__ out)
+{
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= n) return;
+    RunBlock rb{};
+    rb.seed = seed;
+    rb.chain_offset = chain_offset;
+    PhiloxDraws<LaneVec<2>> dr;
+    dr.init(rb, c, d);
+    dr.begin_step(kInitStep);
+    double ss = 0.0;
+    for (int j = 0; 2 * j < d; ++j) {
+        double u0, u1, z0, z1;
+        dr.block(1u + (uint32_t)j, u0, u1);
+        box_muller(u0, u1, z0, z1);
+        out[(size_t)(2 * j) * n + c] = z0;
+        ss = fma(z0, z0, ss);
+        if (2 * j + 1 < d) {
+            out[(size_t)(2 * j + 1) * n + c] = z1;
+            ss = fma(z1, z1, ss);
+        }
+    }
+    const double nrm = sqrt(ss) + 1e-100;  // sphere.py:14
+    for (int j = 0; j < d; ++j) out[(size_t)j * n + c] = out[(size_t)j * n + c] / nrm;
+}
+
+}  // namespace gsss
+
+// ==========================================================================================
+// extern "C"
+// ==========================================================================================
+using namespace gsss;
+
+struct gsss_target {
+    int device;
+    TargetBlock tb;
+    double *blob_dev;
+    size_t blob_doubles;
+};
+
+extern "C" {
+
+int gsss_abi_version(void) { return GSSS_ABI_VERSION; }
+
+const char *gsss_last_error(void) { return g_err; }
+
+int gsss_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **out)
+{
+    if (!desc || !out) {
+        set_error("null argument");
+        return GSSS_E_INVALID;
+    }
+    *out = nullptr;
+    const int d = desc->d, k = desc->k;
+    if (d < 2) {
+        set_error("d must be >= 2 (got %d)", d);
+        return GSSS_E_INVALID;
+    }
+    std::vector<double> blob;
+    switch (desc->kind) {
+    case GSSS_VMF_MIXTURE:
+        if (k < 1 || !desc->mu || !desc->logc) {
+            set_error("vMF mixture needs k >= 1, mu and logc");
+            return GSSS_E_INVALID;
+        }
+        blob.assign(desc->mu, desc->mu + (size_t)k * d);
+        blob.insert(blob.end(), desc->logc, desc->logc + k);
+        break;
+    case GSSS_BINGHAM:
+        if (!desc->A) {
+            set_error("Bingham needs A");
+            return GSSS_E_INVALID;
+        }
+        blob.assign(desc->A, desc->A + (size_t)d * d);
+        break;
+    case GSSS_CURVE_VMF: {
+        if (k < 2 || !desc->knots) {
+            set_error("curve-vMF needs k >= 2 knots");
+            return GSSS_E_INVALID;
+        }
+        blob.assign(desc->knots, desc->knots + (size_t)k * d);
+        // per segment: theta = distance(a, b) and its cos / sin / sin + 1e-10 -- the x-independent
+        // quantities distance_slerp recomputes on every call (spherical_curve.py:28-31)
+        for (int s = 0; s + 1 < k; ++s) {
+            const double *a = desc->knots + (size_t)s * d, *b = a + d;
+            double ab = 0.0;
+            for (int i = 0; i < d; ++i) ab += a[i] * b[i];
+            ab = ab < -1.0 ? -1.0 : (ab > 1.0 ? 1.0 : ab);
+            const double theta = std::acos(ab);
+            blob.push_back(theta);
+            blob.push_back(std::cos(theta));
+            blob.push_back(std::sin(theta));
+            blob.push_back(std::sin(theta) + 1e-10);
+        }
+        break;
+    }
+    default:
+        set_error("unknown target kind %d", desc->kind);
+        return GSSS_E_INVALID;
+    }
+    if (select_vec(d, 0) < 0) return GSSS_E_UNSUPPORTED;
+
+    int ndev = gsss_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("device %d not available (%d HIP devices visible)", device, ndev);
+        return GSSS_E_NO_DEVICE;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    gsss_target *t = new (std::nothrow) gsss_target();
+    if (!t) {
+        set_error("out of host memory");
+        return GSSS_E_INVALID;
+    }
+    t->device = device;
+    t->blob_doubles = blob.size();
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->blob_dev), blob.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(t->blob_dev, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("copying target parameters failed: %s", hipGetErrorString(e));
+        if (t->blob_dev) (void)hipFree(t->blob_dev);
+        delete t;
+        return GSSS_E_HIP;
+    }
+    t->tb.blob = t->blob_dev;
+    t->tb.kind = desc->kind;
+    t->tb.d = d;
+    t->tb.k = k;
+    t->tb.dpad = 0;
+    t->tb.kappa = desc->kappa;
+    *out = t;
+    return GSSS_OK;
+}
+
+int gsss_target_destroy(gsss_target *t)
+{
+    if (!t) return GSSS_OK;
+    DeviceGuard guard(t->device);
+    if (t->blob_dev) (void)hipFree(t->blob_dev);
+    delete t;
+    return GSSS_OK;
+}
+
+int gsss_target_dim(const gsss_target *t) { return t ? t->tb.d : GSSS_E_INVALID; }
+
+int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *out_dev, void *stream)
+{
+    if (!t || n < 0 || (n > 0 && (!x_dev || !out_dev))) {
+        set_error("bad argument to gsss_logprob");
+        return GSSS_E_INVALID;
+    }
+    if (n == 0) return GSSS_OK;
+    const int vec = select_vec(t->tb.d, 0);
+    if (vec < 0) return vec;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return GSSS_E_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (t->tb.kind) {
+    case GSSS_VMF_MIXTURE: return launch_logprob<VmfMixture>(vec, t->tb, x_dev, n, out_dev, st);
+    case GSSS_BINGHAM: return launch_logprob<Bingham>(vec, t->tb, x_dev, n, out_dev, st);
+    case GSSS_CURVE_VMF: return launch_logprob<CurveVmf>(vec, t->tb, x_dev, n, out_dev, st);
+    }
+    set_error("corrupt target");
+    return GSSS_E_INVALID;
+}
+
+int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
+{
+    if (!t || !a) {
+        set_error("null argument");
+        return GSSS_E_INVALID;
+    }
+    if (a->n_chains < 0 || a->n_steps < 0 || a->thin < 1 || a->max_tries < 1) {
+        set_error("need n_chains >= 0, n_steps >= 0, thin >= 1, max_tries >= 1");
+        return GSSS_E_INVALID;
+    }
+    if (a->sampler != GSSS_SHRINK && a->sampler != GSSS_REJECT) {
+        set_error("unknown sampler %d", a->sampler);
+        return GSSS_E_INVALID;
+    }
+    if (a->mode != GSSS_MODE_EXACT) {
+        set_error("mode %d is not built into this library", a->mode);
+        return GSSS_E_UNSUPPORTED;
+    }
+    if (a->chain_offset + (uint64_t)a->n_chains > (1ull << 48) || a->step_offset + (uint64_t)a->n_steps >= kInitStep) {
+        set_error("chain / step ids exceed the 48-bit counter space");
+        return GSSS_E_INVALID;
+    }
+    if (a->n_chains == 0) return GSSS_OK;
+    if (!a->state_dev) {
+        set_error("state_dev is null");
+        return GSSS_E_INVALID;
+    }
+    if (a->replay_dev && a->replay_stride < 1) {
+        set_error("replay_stride must be >= 1");
+        return GSSS_E_INVALID;
+    }
+    const int vec = select_vec(t->tb.d, a->variant);
+    if (vec < 0) return vec;
+    RunBlock rb;
+    rb.state = a->state_dev;
+    rb.samples = a->samples_dev;
+    rb.n_reject = a->n_reject_dev;
+    rb.n_tries = a->n_tries_dev;
+    rb.err = a->err_dev;
+    rb.replay = a->replay_dev;
+    rb.replay_stride = a->replay_stride;
+    rb.n_chains = a->n_chains;
+    rb.n_steps = a->n_steps;
+    rb.thin = a->thin;
+    rb.seed = a->seed;
+    rb.chain_offset = a->chain_offset;
+    rb.step_offset = a->step_offset;
+    rb.sampler = a->sampler;
+    rb.max_tries = a->max_tries;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return GSSS_E_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool replay = a->replay_dev != nullptr;
+    switch (t->tb.kind) {
+    case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, replay, t->tb, rb, st);
+    case GSSS_BINGHAM: return launch_run<Bingham>(vec, replay, t->tb, rb, st);
+    case GSSS_CURVE_VMF: return launch_run<CurveVmf>(vec, replay, t->tb, rb, st);
+    }
+    set_error("corrupt target");
+    return GSSS_E_INVALID;
+}
+
+const char *gsss_variant_name(const gsss_target *t, int32_t /*mode*/, int32_t variant)
+{
+    if (!t) return "";
+    const int vec = select_vec(t->tb.d, variant);
+    if (vec < 0) return "";
+    int n;
+    const VecInfo *v = vec_table(&n);
+    for (int i = 0; i < n; ++i)
+        if (v[i].id == vec) return v[i].name;
+    return "";
+}
+
+int gsss_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int32_t d, double *state_dev, int device,
+                       void *stream)
+{
+    if (n < 0 || d < 2 || (n > 0 && !state_dev)) {
+        set_error("bad argument to gsss_sample_sphere");
+        return GSSS_E_INVALID;
+    }
+    if (n == 0) return GSSS_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    const int64_t grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(sample_sphere_kernel, dim3((unsigned)grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       seed, chain_offset, n, (int)d, state_dev);
+    GSSS_HIP_TRY(hipGetLastError());
+    return GSSS_OK;
+}
+
+int gsss_rows_to_components(const double *in_dev, double *out_dev, int64_t n, int32_t d, int device, void *stream)
+{
+    return transpose(in_dev, out_dev, n, d, device, static_cast<hipStream_t>(stream));
+}
+
+int gsss_components_to_rows(const double *in_dev, double *out_dev, int64_t n, int32_t d, int device, void *stream)
+{
+    return transpose(in_dev, out_dev, d, n, device, static_cast<hipStream_t>(stream));
+}
+
+int gsss_samples_to_chains(const double *in_dev, double *out_dev, int64_t n, int64_t n_keep, int32_t d, int device,
+                           void *stream)
+{
+    // [n_keep][d][n] -> [n][n_keep][d] is the transpose of an [n_keep*d][n] matrix
+    return transpose(in_dev, out_dev, n_keep * d, n, device, static_cast<hipStream_t>(stream));
+}
+
+int gsss_malloc(void **out_dev, size_t bytes, int device)
+{
+    if (!out_dev) {
+        set_error("null argument");
+        return GSSS_E_INVALID;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipMalloc(out_dev, bytes ? bytes : 1));
+    return GSSS_OK;
+}
+
+int gsss_free(void *p_dev, int device)
+{
+    if (!p_dev) return GSSS_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipFree(p_dev));
+    return GSSS_OK;
+}
+
+int gsss_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device, void *stream)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GSSS_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+    GSSS_HIP_TRY(hipStreamSynchronize(st));
+    return GSSS_OK;
+}
+
+int gsss_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GSSS_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+    GSSS_HIP_TRY(hipStreamSynchronize(st));
+    return GSSS_OK;
+}
+
+int gsss_memset(void *dst_dev, int value, size_t bytes, int device, void *stream)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, static_cast<hipStream_t>(stream)));
+    return GSSS_OK;
+}
+
+int gsss_stream_synchronize(int device, void *stream)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return GSSS_OK;
+}
+
+}  // extern "C"

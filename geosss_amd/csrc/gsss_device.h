@@ -1,0 +1,561 @@
+// gsss_device.h -- device-side building blocks of the many-chain geodesic slice sampler.
+// gfx950 (CDNA4) only: 64-wide wavefronts, FP64 VALU, LDS-staged target parameters.
+//
+// Reference semantics followed (paths relative to the geosss repository):
+//   proposal + shrinkage loop   geosss/mcmc.py:382-401   (rejection variant :357-374)
+//   spherical_projection        geosss/sphere.py:10-33
+//   vMF mixture log_prob        geosss/distributions.py:156-157, 218-221
+//   Bingham log_prob            geosss/distributions.py:84-86
+//   curve-vMF log_prob          geosss/distributions.py:272-275, spherical_curve.py:10-32, 95-102
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsss.h"
+
+namespace gsss {
+
+constexpr int kBlock = 256;             // threads per workgroup = 4 wavefronts
+constexpr double kTwoPi = 6.283185307179586;  // 2*np.pi
+
+// ------------------------------------------------------------------------------------------
+// Kernel-argument blocks (plain data, passed by value)
+// ------------------------------------------------------------------------------------------
+struct TargetBlock {
+    const double *blob;  // device parameter blob, layout per kind (see gsss_capi.hip: build_blob)
+    int32_t kind, d, k, dpad;
+    double kappa;
+};
+
+struct RunBlock {
+    double *state;
+    double *samples;
+    int64_t *n_reject;
+    int64_t *n_tries;
+    int32_t *err;
+    const double *replay;
+    int64_t replay_stride;
+    int64_t n_chains, n_steps, thin;
+    uint64_t seed, chain_offset, step_offset;
+    int32_t sampler, max_tries;
+};
+
+// ------------------------------------------------------------------------------------------
+// RNG stream (DESIGN.md "RNG stream"): Philox4x32-10, counter = (block, step_lo, chain_lo,
+// chain_hi16 | step_hi16 << 16), key = seed.  Integer part is bit-identical to the oracle.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b)
+{
+    return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * 0x1.0p-53;
+}
+
+// Box-Muller pair from two uniforms of one stream block
+__device__ __forceinline__ void box_muller(double u0, double u1, double &z0, double &z1)
+{
+    const double r = sqrt(-2.0 * log(1.0 - u0));
+    double s, c;
+    sincospi(2.0 * u1, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+constexpr uint64_t kInitStep = 0xFFFFFFFFFFFFull;  // reserved step id: initial states (gsss_sample_sphere)
+
+// ------------------------------------------------------------------------------------------
+// Vector policies: how the d components of one chain map onto lanes.
+//   LaneVec<D>   : one lane per chain, all D components in that lane's registers.
+//   CoopVec<L,S> : L lanes per chain (L | 64), S register slots per lane, components dealt in
+//                  pairs (2p, 2p+1), pair p = g + L*ip, so each lane owns whole Box-Muller pairs.
+// Slots beyond d hold zeros (and zero-padded parameters), so dots need no guards.
+// ------------------------------------------------------------------------------------------
+template <int D_>
+struct LaneVec {
+    static constexpr int L = 1;
+    static constexpr int N = D_;
+    static constexpr int DPAD = D_;
+    static constexpr bool kExactDim = true;  // requires d == D_
+    __device__ static __forceinline__ int comp(int /*g*/, int i) { return i; }
+    __device__ static __forceinline__ double reduce(double v) { return v; }
+};
+
+template <int L_, int S_>
+struct CoopVec {
+    static_assert(S_ % 2 == 0, "slots come in pairs");
+    static constexpr int L = L_;
+    static constexpr int N = S_;
+    static constexpr int DPAD = L_ * S_;
+    static constexpr bool kExactDim = false;  // any d <= DPAD
+    __device__ static __forceinline__ int comp(int g, int i) { return 2 * (g + L_ * (i >> 1)) + (i & 1); }
+    // xor-butterfly over the L lanes of a group: every lane ends with the same bits
+    __device__ static __forceinline__ double reduce(double v)
+    {
+#pragma unroll
+        for (int m = 1; m < L_; m <<= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+};
+
+template <class V>
+__device__ __forceinline__ double vdot(const double (&a)[V::N], const double (&b)[V::N])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < V::N; ++i) s = fma(a[i], b[i], s);
+    return V::reduce(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Draw sources
+// ------------------------------------------------------------------------------------------
+template <class V>
+struct PhiloxDraws {
+    static constexpr bool kReplay = false;
+    uint32_t k0, k1, c1, c2, c3, chain_hi;
+    int d, t;
+    double cached;
+    bool exhausted;
+
+    __device__ __forceinline__ void init(const RunBlock &a, int64_t chain_local, int d_)
+    {
+        const uint64_t chain = a.chain_offset + (uint64_t)chain_local;
+        k0 = (uint32_t)a.seed;
+        k1 = (uint32_t)(a.seed >> 32);
+        c2 = (uint32_t)chain;
+        chain_hi = (uint32_t)((chain >> 32) & 0xFFFFu);
+        d = d_;
+        exhausted = false;
+    }
+    __device__ __forceinline__ void begin_step(uint64_t step)
+    {
+        c1 = (uint32_t)step;
+        c3 = chain_hi | ((uint32_t)((step >> 32) & 0xFFFFu) << 16);
+        t = 0;
+    }
+    __device__ __forceinline__ void block(uint32_t blk, double &u0, double &u1) const
+    {
+        uint32_t w[4];
+        philox4x32_10(blk, c1, c2, c3, k0, k1, w);
+        u0 = u53(w[0], w[1]);
+        u1 = u53(w[2], w[3]);
+    }
+    __device__ __forceinline__ void normals(double (&z)[V::N], int g) const
+    {
+#pragma unroll
+        for (int ip = 0; ip < (V::N + 1) / 2; ++ip) {
+            const int c0 = V::comp(g, 2 * ip);
+            double z0 = 0.0, z1 = 0.0;
+            if (c0 < d) {
+                double u0, u1;
+                block(1u + (uint32_t)(c0 >> 1), u0, u1);
+                box_muller(u0, u1, z0, z1);
+            }
+            z[2 * ip] = z0;
+            if (2 * ip + 1 < V::N) z[2 * ip + 1] = (c0 + 1 < d) ? z1 : 0.0;
+        }
+    }
+    __device__ __forceinline__ void step_uniforms(double &u_thr, double &u_theta0, bool /*need_theta0*/) const
+    {
+        block(0u, u_thr, u_theta0);
+    }
+    __device__ __forceinline__ double next_try()
+    {
+        const int tt = t++;
+        if (tt & 1) return cached;
+        double u0;
+        block(1u + (uint32_t)((d + 1) >> 1) + (uint32_t)(tt >> 1), u0, cached);
+        return u0;
+    }
+};
+
+template <class V>
+struct ReplayDraws {
+    static constexpr bool kReplay = true;
+    const double *p;
+    int64_t len, cur;
+    int d;
+    bool exhausted;
+
+    __device__ __forceinline__ void init(const RunBlock &a, int64_t chain_local, int d_)
+    {
+        p = a.replay + chain_local * a.replay_stride;
+        len = a.replay_stride;
+        cur = 0;
+        d = d_;
+        exhausted = false;
+    }
+    __device__ __forceinline__ void begin_step(uint64_t) {}
+    __device__ __forceinline__ double take()
+    {
+        if (cur >= len) {
+            exhausted = true;
+            return 0.5;
+        }
+        return p[cur++];
+    }
+    __device__ __forceinline__ void normals(double (&z)[V::N], int g)
+    {
+        const bool ok = cur + d <= len;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) {
+            const int c = V::comp(g, i);
+            z[i] = (c < d) ? (ok ? p[cur + c] : 0.5) : 0.0;
+        }
+        if (ok)
+            cur += d;
+        else {
+            cur = len;
+            exhausted = true;
+        }
+    }
+    __device__ __forceinline__ void step_uniforms(double &u_thr, double &u_theta0, bool need_theta0)
+    {
+        u_thr = take();
+        u_theta0 = need_theta0 ? take() : 0.0;
+    }
+    __device__ __forceinline__ double next_try() { return take(); }
+};
+
+// ------------------------------------------------------------------------------------------
+// Targets.  Each stages its parameters in LDS (zero-padded to V::DPAD columns) and evaluates
+// log_prob(y) from the components of y held by the calling lane group.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_fill(double *dst, int n_rows, int dpad, const double *src, int d)
+{
+    // rows of length d in global memory -> rows of length dpad in LDS, zero padded
+    for (int i = threadIdx.x; i < n_rows * dpad; i += kBlock) {
+        const int r = i / dpad, c = i - r * dpad;
+        dst[i] = (c < d) ? src[(size_t)r * d + c] : 0.0;
+    }
+}
+
+template <class V>
+struct VmfMixture {
+    const double *mu;    // LDS [K][DPAD]
+    const double *logc;  // LDS [K]
+    int K;
+
+    __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return (size_t)k * V::DPAD + k; }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        K = tb.k;
+        lds_fill(lds, K, V::DPAD, tb.blob, tb.d);
+        double *lc = lds + (size_t)K * V::DPAD;
+        for (int i = threadIdx.x; i < K; i += kBlock) lc[i] = tb.blob[(size_t)K * tb.d + i];
+        mu = lds;
+        logc = lc;
+    }
+    __device__ __forceinline__ double comp_logp(const double (&y)[V::N], int g, int k) const
+    {
+        const double *m = mu + (size_t)k * V::DPAD;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) s = fma(y[i], m[V::comp(g, i)], s);
+        return V::reduce(s) + logc[k];
+    }
+    // logsumexp_k( y.mu_k + logc_k )
+    __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
+    {
+        double amax = -INFINITY;
+        for (int k = 0; k < K; ++k) amax = fmax(amax, comp_logp(y, g, k));
+        if (!(amax > -INFINITY) || amax == INFINITY) return amax;
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += exp(comp_logp(y, g, k) - amax);
+        return amax + log(s);
+    }
+    static constexpr int kScratchPerChain = 0;
+};
+
+template <class V>
+struct Bingham {
+    const double *A;  // LDS [DPAD][DPAD], zero padded
+    __host__ __device__ static size_t lds_doubles(int /*k*/, int /*d*/) { return (size_t)V::DPAD * V::DPAD; }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        for (int i = threadIdx.x; i < V::DPAD * V::DPAD; i += kBlock) {
+            const int r = i / V::DPAD, c = i - r * V::DPAD;
+            lds[i] = (r < tb.d && c < tb.d) ? tb.blob[(size_t)r * tb.d + c] : 0.0;
+        }
+        A = lds;
+    }
+    // sum_j (sum_i y_i A_ij) y_j
+    __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double *scratch) const
+    {
+        double s = 0.0;
+        if constexpr (V::L == 1) {
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) {
+                double xa = 0.0;
+#pragma unroll
+                for (int i = 0; i < V::N; ++i) xa = fma(y[i], A[i * V::DPAD + j], xa);
+                s = fma(xa, y[j], s);
+            }
+            return s;
+        } else {
+            // publish y to the group's LDS row, then every lane forms (yA)_j for its own slots j
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) scratch[V::comp(g, i)] = y[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double xa[V::N];
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) xa[j] = 0.0;
+            for (int i = 0; i < V::DPAD; ++i) {
+                const double yi = scratch[i];
+#pragma unroll
+                for (int j = 0; j < V::N; ++j) xa[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], xa[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) s = fma(xa[j], y[j], s);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            return V::reduce(s);
+        }
+    }
+    static constexpr int kScratchPerChain = (V::L == 1) ? 0 : V::DPAD + 1;
+};
+
+template <class V>
+struct CurveVmf {
+    const double *knots;  // LDS [K][DPAD]
+    const double *seg;    // LDS [K-1][4] : theta, cos(theta), sin(theta), sin(theta)+1e-10  (spherical_curve.py:28-31)
+    int K;
+    double kappa;
+    __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return (size_t)k * V::DPAD + 4 * (size_t)(k - 1); }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        K = tb.k;
+        kappa = tb.kappa;
+        lds_fill(lds, K, V::DPAD, tb.blob, tb.d);
+        double *sg = lds + (size_t)K * V::DPAD;
+        for (int i = threadIdx.x; i < 4 * (K - 1); i += kBlock) sg[i] = tb.blob[(size_t)K * tb.d + i];
+        knots = lds;
+        seg = sg;
+    }
+    __device__ __forceinline__ double kdot(const double (&y)[V::N], int g, int k) const
+    {
+        const double *a = knots + (size_t)k * V::DPAD;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) s = fma(a[V::comp(g, i)], y[i], s);
+        return V::reduce(s);
+    }
+    // kappa * (y . nearest(y)); nearest = closest point of the first segment of minimal distance
+    __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
+    {
+        double best = INFINITY, best_dot = 0.0;
+        double ay = kdot(y, g, 0);
+        for (int s = 0; s + 1 < K; ++s) {
+            const double by = kdot(y, g, s + 1);
+            const double theta = seg[4 * s], ct = seg[4 * s + 1], st = seg[4 * s + 2], den = seg[4 * s + 3];
+            double t = atan2(by - ay * ct, ay * st);
+            t = fmin(fmax(t, 0.0), theta);
+            const double sa = sin(theta - t), sb = sin(t);
+            const double *a = knots + (size_t)s * V::DPAD, *b = a + V::DPAD;
+            double xy = 0.0;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) {
+                const int c = V::comp(g, i);
+                const double near_i = (sa * a[c] + sb * b[c]) / den;
+                xy = fma(y[i], near_i, xy);
+            }
+            xy = V::reduce(xy);
+            const double dist = acos(fmin(fmax(xy, -1.0), 1.0));
+            if (dist < best) {
+                best = dist;
+                best_dot = xy;
+            }
+            ay = by;
+        }
+        return kappa * best_dot;
+    }
+    static constexpr int kScratchPerChain = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// The sampler: one lane group per chain, step-synchronous.
+// ------------------------------------------------------------------------------------------
+template <class V, class T>
+__host__ __device__ constexpr size_t scratch_doubles()
+{
+    return (size_t)T::kScratchPerChain * (kBlock / V::L);
+}
+
+template <class V, template <class> class TT, template <class> class DR>
+__global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
+{
+    using T = TT<V>;
+    using Draws = DR<V>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    T tgt;
+    tgt.stage(lds, tb);
+    double *scratch = lds + T::lds_doubles(tb.k, tb.d) + (size_t)T::kScratchPerChain * (threadIdx.x / V::L);
+    __syncthreads();
+
+    const int d = tb.d;
+    const int g = threadIdx.x % V::L;
+    const int64_t n = a.n_chains;
+    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / V::L) + threadIdx.x / V::L;
+    const bool active = c_raw < n;
+    const int64_t c = active ? c_raw : n - 1;  // tail lanes shadow the last chain and store nothing
+
+    double x[V::N];
+#pragma unroll
+    for (int i = 0; i < V::N; ++i) {
+        const int cc = V::comp(g, i);
+        x[i] = (cc < d) ? a.state[(size_t)cc * n + c] : 0.0;
+    }
+    Draws dr;
+    dr.init(a, c, d);
+
+    double px = tgt.logp(x, g, scratch);
+    int err = 0;
+    int64_t n_rej = 0, n_try = 0;
+    const bool shrink = a.sampler == GSSS_SHRINK;
+    int64_t until_keep = a.thin, row = 0;
+
+    for (int64_t s = 0; s < a.n_steps; ++s) {
+        if (!(px > -INFINITY)) {  // also catches NaN
+            err |= GSSS_CHAIN_NONFINITE;
+            break;
+        }
+        dr.begin_step(a.step_offset + (uint64_t)s);
+
+        // u = spherical_projection(z, x)   (sphere.py:29-33)
+        double u[V::N];
+        dr.normals(u, g);  // u holds z for now
+        {
+            const double nx = sqrt(vdot<V>(x, x)) + 1e-100;
+            double nrm[V::N];
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) nrm[i] = x[i] / nx;
+            const double cz = vdot<V>(u, nrm);
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) u[i] = fma(-cz, nrm[i], u[i]);
+            const double nw = sqrt(vdot<V>(u, u)) + 1e-100;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) u[i] = u[i] / nw;
+        }
+        double u_thr, u_th0;
+        dr.step_uniforms(u_thr, u_th0, shrink);
+        const double thr = px + log(u_thr);  // mcmc.py:389
+        double lo, hi;
+        if (shrink) {
+            hi = kTwoPi * u_th0;             // mcmc.py:391
+            lo = hi - kTwoPi;                // mcmc.py:392
+        } else {
+            lo = 0.0;                        // mcmc.py:367
+            hi = kTwoPi;
+        }
+
+        int t = 0;
+        int step_err = 0;
+        for (;;) {
+            if (t >= a.max_tries) {
+                step_err = GSSS_CHAIN_MAX_TRIES;
+                break;
+            }
+            const double theta = lo + (hi - lo) * dr.next_try();  // mcmc.py:395
+            double sn, cs;
+            sincos(theta, &sn, &cs);
+            double y[V::N];
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) y[i] = fma(sn, u[i], cs * x[i]);  // mcmc.py:396
+            const double py = tgt.logp(y, g, scratch);
+            ++t;
+            if (py > thr) {                                       // mcmc.py:397
+#pragma unroll
+                for (int i = 0; i < V::N; ++i) x[i] = y[i];
+                px = py;
+                if (Draws::kReplay && dr.exhausted) step_err = GSSS_CHAIN_REPLAY_EXHAUSTED;
+                break;
+            }
+            if (shrink) {                                         // mcmc.py:400
+                if (theta < 0.0)
+                    lo = theta;
+                else
+                    hi = theta;
+            }
+            if (Draws::kReplay && dr.exhausted) {
+                step_err = GSSS_CHAIN_REPLAY_EXHAUSTED;
+                break;
+            }
+        }
+        n_try += t;
+        n_rej += step_err ? t : t - 1;
+        err |= step_err;
+
+        if (a.samples != nullptr && --until_keep == 0) {
+            until_keep = a.thin;
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < V::N; ++i) {
+                    const int cc = V::comp(g, i);
+                    if (cc < d) a.samples[((size_t)row * d + cc) * n + c] = x[i];
+                }
+            }
+            ++row;
+        }
+        if (step_err) break;
+    }
+
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) {
+            const int cc = V::comp(g, i);
+            if (cc < d) a.state[(size_t)cc * n + c] = x[i];
+        }
+        if (g == 0) {
+            if (a.n_reject) a.n_reject[c] += n_rej;
+            if (a.n_tries) a.n_tries[c] += n_try;
+            if (a.err && err) a.err[c] |= err;
+        }
+    }
+}
+
+// Distribution.log_prob for rows of a row-major [n][d] array
+template <class V, template <class> class TT>
+__global__ void __launch_bounds__(kBlock) logprob_kernel(TargetBlock tb, const double *__restrict__ xin, int64_t n,
+                                                         double *__restrict__ out)
+{
+    using T = TT<V>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    T tgt;
+    tgt.stage(lds, tb);
+    double *scratch = lds + T::lds_doubles(tb.k, tb.d) + (size_t)T::kScratchPerChain * (threadIdx.x / V::L);
+    __syncthreads();
+    const int d = tb.d;
+    const int g = threadIdx.x % V::L;
+    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / V::L) + threadIdx.x / V::L;
+    const bool active = c_raw < n;
+    const int64_t c = active ? c_raw : n - 1;
+    double x[V::N];
+#pragma unroll
+    for (int i = 0; i < V::N; ++i) {
+        const int cc = V::comp(g, i);
+        x[i] = (cc < d) ? xin[(size_t)c * d + cc] : 0.0;
+    }
+    const double p = tgt.logp(x, g, scratch);
+    if (active && g == 0) out[c] = p;
+}
+
+}  // namespace gsss

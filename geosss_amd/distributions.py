@@ -1,0 +1,301 @@
+"""Target distributions of the geodesic slice sampler, API-compatible with
+geosss/distributions.py for the families the hot path covers:
+
+    VonMisesFisher(mu)                      distributions.py:117-160
+    MixtureModel(components, weights=None)  distributions.py:209-227
+    Bingham(A), random_bingham(...)         distributions.py:36-103, 230-258
+    CurvedVonMisesFisher(curve, kappa)      distributions.py:261-278
+    SlerpCurve(knots), brownian_curve(...)  spherical_curve.py:74-129
+
+The objects are parameter carriers: they keep the same attributes as the reference
+(`.mu`, `.pdfs`, `.weights`, `.A`, `.curve.knots`, `.kappa`, `.d`) and hand a packed
+parameter block to the HIP library.  `log_prob` accepts a point (d,) or rows (n, d), as in
+the reference, and is evaluated ON THE GPU through the C ABI (`gsss_logprob`); there is no
+host implementation to fall back to.  `pdf.log_prob.num_calls` / `.reset_counters()` keep
+the reference's call-counter protocol (utils.py:137-185); the samplers add the number of
+log-density evaluations their kernels performed.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from scipy.special import i0, ive
+
+from . import _lib
+from .sphere import _device_index, current_stream_ptr
+
+__all__ = ["Distribution", "VonMisesFisher", "MixtureModel", "Bingham", "CurvedVonMisesFisher", "SlerpCurve",
+           "random_bingham", "brownian_curve", "counted"]
+
+
+def counted(fn):
+    """Call counter with the reference's protocol: `obj.method.num_calls`, `obj.method.reset_counters()`
+    (the attributes live on the underlying function, so they are shared by all instances of the
+    class, exactly like geosss.utils.count_calls)."""
+
+    def method(self, *args, **kwargs):
+        method.num_calls += 1
+        return fn(self, *args, **kwargs)
+
+    def reset_counters():
+        method.num_calls = 0
+
+    method.num_calls = 0
+    method.reset_counters = reset_counters
+    method.__name__ = fn.__name__
+    method.__doc__ = fn.__doc__
+    return method
+
+
+def _as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def log_bessel_i0(kappa):
+    """log(i0(kappa)).  The reference evaluates np.log(i0(kappa)) (distributions.py:157), which
+    overflows to +inf for kappa >~ 713.99 and then never terminates (mcmc.py:394); below that
+    threshold we return the very same expression, above it the overflow-free equivalent
+    log(ive(0, kappa)) + kappa."""
+    kappa = np.asarray(kappa, dtype=np.float64)
+    with np.errstate(over="ignore"):
+        direct = np.log(i0(kappa))
+    safe = np.log(ive(0, kappa)) + kappa
+    return np.where(np.isfinite(direct), direct, safe)
+
+
+class _DeviceTarget:
+    """Owns one gsss_target handle (device parameter block)."""
+
+    def __init__(self, desc_arrays, kind, d, k, kappa, device):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = device
+        self._keep = desc_arrays  # keep the host arrays alive during create
+        desc = _lib.TargetDesc(kind, d, k, 0,
+                               *[a.ctypes.data_as(C.c_void_p) if a is not None else None for a in desc_arrays],
+                               float(kappa))
+        h = C.c_void_p()
+        _lib.check(self.lib.gsss_target_create(C.byref(desc), device, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.gsss_target_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Distribution:
+    """Base class: packing + device evaluation shared by all targets."""
+
+    def _pack(self):
+        """-> (kind, d, k, kappa, (mu, logc, A, knots))"""
+        raise NotImplementedError
+
+    def _device_target(self, device=None):
+        dev = _device_index(device)
+        cache = self.__dict__.setdefault("_targets", {})
+        if dev not in cache:
+            kind, d, k, kappa, arrays = self._pack()
+            cache[dev] = _DeviceTarget(arrays, kind, d, k, kappa, dev)
+        return cache[dev]
+
+    def _invalidate(self):
+        self.__dict__.pop("_targets", None)
+
+    def _log_prob_device(self, x):
+        """x: numpy (d,), (n, d) or a CUDA float64 tensor (n, d) -> same kind of container."""
+        if isinstance(x, torch.Tensor):
+            if not x.is_cuda:
+                raise ValueError("torch input to log_prob must live on the GPU")
+            tgt = self._device_target(x.device)
+            xt = x.to(torch.float64).contiguous()
+            single = xt.ndim == 1
+            xt2 = xt[None] if single else xt
+            if xt2.ndim != 2 or xt2.shape[1] != self.d:
+                raise ValueError(f"expected (..., {self.d}) input")
+            out = torch.empty(xt2.shape[0], dtype=torch.float64, device=xt.device)
+            dev = _device_index(xt.device)
+            _lib.check(tgt.lib.gsss_logprob(tgt.handle, xt2.data_ptr(), xt2.shape[0], out.data_ptr(),
+                                            current_stream_ptr(dev)))
+            return out[0] if single else out
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim not in (1, 2) or x.shape[-1] != self.d:
+            raise ValueError(f"expected (d,) or (n, d) input with d={self.d}")  # distributions.py:84
+        _lib.require_device()
+        dev = _device_index(None)
+        xt = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(x))).to(f"cuda:{dev}")
+        out = self._log_prob_device(xt).cpu().numpy()
+        return float(out[0]) if x.ndim == 1 else out
+
+    def log_prob(self, x):
+        raise NotImplementedError
+
+    def gradient(self, x):
+        raise NotImplementedError("gradients are not on the slice sampler's path")
+
+
+class VonMisesFisher(Distribution):
+    """vMF(x) ~ exp(mu.x);  log_prob = x.mu - log(2 pi) - log(i0(|mu|))  (distributions.py:156-157).
+    `mu` is stored unnormalised, kappa = |mu| (distributions.py:126-136)."""
+
+    def __init__(self, mu):
+        self.mu = np.array(mu, dtype=np.float64)
+
+    @property
+    def d(self):
+        return self.mu.size
+
+    @property
+    def kappa(self):
+        return float(np.linalg.norm(self.mu))
+
+    @property
+    def mode(self):
+        return self.mu / (np.linalg.norm(self.mu) + 1e-100)
+
+    @property
+    def max_log_prob(self):
+        return self.kappa
+
+    def _log_const(self):
+        return -np.log(2 * np.pi) - float(log_bessel_i0(self.kappa))
+
+    def _pack(self):
+        mu = _as_f64(self.mu[None])
+        logc = _as_f64([self._log_const()])
+        return _lib.VMF_MIXTURE, self.d, 1, 0.0, (mu, logc, None, None)
+
+    @counted
+    def log_prob(self, x):
+        return self._log_prob_device(x)
+
+    def gradient(self, x):
+        return self.mu
+
+
+class MixtureModel(Distribution):
+    """log_prob = logsumexp_k(log_prob_k(x) + log w_k), weights normalised to one
+    (distributions.py:211-221).  Components must be VonMisesFisher of one dimension."""
+
+    def __init__(self, components, weights=None):
+        self.pdfs = list(components)
+        if not self.pdfs or not all(isinstance(p, VonMisesFisher) for p in self.pdfs):
+            raise TypeError("the HIP path covers mixtures of VonMisesFisher components")
+        if len({p.d for p in self.pdfs}) != 1:
+            raise ValueError("all components must share the dimension")
+        w = np.ones(len(self.pdfs)) if weights is None else np.array(weights, dtype=np.float64)
+        if w.shape != (len(self.pdfs),):
+            raise ValueError("one weight per component")
+        self.weights = w / w.sum()
+
+    @property
+    def d(self):
+        return self.pdfs[0].d
+
+    def _pack(self):
+        mu = _as_f64([p.mu for p in self.pdfs])
+        with np.errstate(divide="ignore"):
+            logw = np.log(self.weights)
+        logc = _as_f64([p._log_const() for p in self.pdfs]) + logw
+        return _lib.VMF_MIXTURE, self.d, len(self.pdfs), 0.0, (mu, _as_f64(logc), None, None)
+
+    @counted
+    def log_prob(self, x):
+        return self._log_prob_device(x)
+
+
+class Bingham(Distribution):
+    """p(x) ~ exp(x^T A x) with symmetric A;  log_prob = sum((x @ A) * x)  (distributions.py:67-86)."""
+
+    def __init__(self, A):
+        A = np.array(A, dtype=np.float64)
+        if A.ndim != 2 or A.shape[0] != A.shape[1] or not np.allclose(A, A.T):
+            raise ValueError("A must be a symmetric square matrix")  # distributions.py:68
+        self.A = A
+        v, U = np.linalg.eigh(A)
+        self.v, self.U = v[::-1], U[:, ::-1]  # descending, as the reference keeps them
+
+    @property
+    def d(self):
+        return len(self.A)
+
+    @property
+    def mode(self):
+        return self.U[:, 0]
+
+    @property
+    def max_log_prob(self):
+        return self.v[0]
+
+    def _pack(self):
+        return _lib.BINGHAM, self.d, 0, 0.0, (None, None, _as_f64(self.A), None)
+
+    @counted
+    def log_prob(self, x):
+        return self._log_prob_device(x)
+
+    def gradient(self, x):
+        return 2 * self.A @ x
+
+
+def random_bingham(d=2, vmax=None, vmin=None, eigensystem=False, seed=None):
+    """Random Bingham target with the construction of distributions.py:230-258, so that the same
+    seed gives the same precision matrix as the reference (e.g. scripts/bingham.py:131 uses
+    d=10, vmax=30, vmin=0, eigensystem=True, seed=6982)."""
+    g = np.random.default_rng(seed)
+    M = g.standard_normal((d, d))
+    spectrum, basis = np.linalg.eigh(M.T @ M)
+    if vmin is not None:
+        spectrum += vmin - spectrum.min()
+    if vmax is not None:
+        spectrum *= vmax / spectrum.max()
+    if eigensystem:
+        basis = np.eye(d)
+    return Bingham((basis * spectrum) @ basis.T)
+
+
+class SlerpCurve:
+    """Piecewise-geodesic curve through `knots` (rows, unit vectors); spherical_curve.py:74-85."""
+
+    def __init__(self, knots):
+        self.knots = np.array(knots, dtype=np.float64)
+        if self.knots.ndim != 2 or self.knots.shape[0] < 2:
+            raise ValueError("need at least two knots")
+
+
+def brownian_curve(n_points=100, dimension=6, step_size=0.05, seed=1234):
+    """Knots of a random walk on the sphere, the construction of spherical_curve.py:105-129
+    (same seed -> same knots as the reference: scripts/curve_vMF.py:577-582)."""
+    g = np.random.default_rng(seed)
+    pts = np.zeros((n_points, dimension))
+    z = g.standard_normal(dimension)
+    pts[0] = z / (np.linalg.norm(z) + 1e-100)
+    for i in range(1, n_points):
+        w = pts[i - 1] + g.normal(size=dimension) * step_size
+        pts[i] = w / (np.linalg.norm(w) + 1e-100)
+    return pts
+
+
+class CurvedVonMisesFisher(Distribution):
+    """log_prob = kappa * x . nearest_point_on_curve(x)  (distributions.py:263-275)."""
+
+    def __init__(self, curve, kappa=100.0):
+        if not hasattr(curve, "knots"):
+            raise TypeError("curve must expose .knots (SlerpCurve)")
+        self.curve = curve
+        self.kappa = float(kappa)
+
+    @property
+    def d(self):
+        return self.curve.knots.shape[-1]
+
+    def _pack(self):
+        knots = _as_f64(self.curve.knots)
+        return _lib.CURVE_VMF, self.d, knots.shape[0], self.kappa, (None, None, None, knots)
+
+    @counted
+    def log_prob(self, x):
+        return self._log_prob_device(x)

@@ -1,0 +1,290 @@
+"""Geodesic slice samplers on the sphere for many chains at once, API-compatible with
+geosss/mcmc.py for the two slice samplers:
+
+    RejectionSphericalSliceSampler(distribution, initial_state, seed=None)   mcmc.py:335-374
+    ShrinkageSphericalSliceSampler(distribution, initial_state, seed=None)   mcmc.py:377-401
+        next(sampler)                                  one transition (of every chain)
+        sampler.sample(n_samples, burnin=0, return_all_samples=False)        mcmc.py:55-77
+        sampler.target / .state / .rng / .n_reject                           mcmc.py:43-45, 355
+
+`initial_state` may be one point (d,) -- then everything has the reference's shapes -- or
+(n_chains, d): then `sample` returns (n_chains, n_samples, d), the (chains, draws, dims)
+convention the reference's harness feeds to its ESS estimator.
+
+All transitions run in the HIP kernels behind `gsss_run` (include/gsss.h); chain states stay
+resident in HBM between calls.  Random numbers come from the library's counter-based stream
+(DESIGN.md "RNG stream"), keyed by `seed`, chain id and step id, so results do not depend on how
+chains are split over devices or steps over calls.  `sampler.rng` is kept as a numpy Generator for
+API compatibility but the kernels do not draw from it.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .sphere import _device_index, current_stream_ptr
+
+__all__ = ["determine_burnin", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler"]
+
+_MODES = {"exact": _lib.MODE_EXACT, "fast": _lib.MODE_FAST}
+_MAX_STEPS_PER_LAUNCH = 4096
+
+
+def determine_burnin(n_samples, burnin):
+    """float = fraction of n_samples, int = count (mcmc.py:13-19)."""
+    if isinstance(burnin, float):
+        if not 0 <= burnin <= 1.0:
+            raise AssertionError("fractional burnin must be in [0, 1]")
+        return int(burnin * n_samples)
+    if burnin < 0:
+        raise AssertionError("burnin must be >= 0")
+    return int(burnin)
+
+
+def seed_to_key(seed):
+    """64-bit Philox key from what np.random.default_rng accepts as `seed` (mcmc.py:45)."""
+    if seed is None:
+        w = np.random.SeedSequence().generate_state(2, np.uint32)
+    elif isinstance(seed, (int, np.integer)):
+        if seed < 0:
+            raise ValueError("seed must be non-negative")
+        if int(seed) < 2**64:
+            return int(seed)
+        w = np.random.SeedSequence(int(seed)).generate_state(2, np.uint32)
+    elif isinstance(seed, np.random.SeedSequence):
+        w = seed.generate_state(2, np.uint32)
+    elif isinstance(seed, np.random.Generator):
+        w = seed.integers(0, 2**32, size=2, dtype=np.uint64)
+    elif isinstance(seed, np.random.BitGenerator):
+        w = np.random.Generator(seed).integers(0, 2**32, size=2, dtype=np.uint64)
+    else:
+        w = np.random.SeedSequence(seed).generate_state(2, np.uint32)
+    return int(w[0]) | (int(w[1]) << 32)
+
+
+class RejectionSphericalSliceSampler:
+    """Geodesic rejection slice sampler (mcmc.py:335-374), many chains."""
+
+    _sampler = _lib.REJECT
+
+    def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="exact", max_tries=None,
+                 chain_offset=0, step_offset=0, variant=0):
+        _lib.require_device()
+        self._lib = _lib.load()
+        self.target = distribution
+        self.rng = np.random.default_rng(seed if not isinstance(seed, np.random.Generator) else None)
+        self.seed = seed_to_key(seed)
+        self.device = _device_index(device)
+        self._tdev = f"cuda:{self.device}"
+        self.mode = mode
+        if mode not in _MODES:
+            raise ValueError(f"mode must be one of {sorted(_MODES)}")
+        self.max_tries = int(max_tries) if max_tries is not None else (1 << 20)
+        self.chain_offset = int(chain_offset)
+        self.variant = int(variant)
+        self._step = int(step_offset)
+        self._target_dev = distribution._device_target(self.device)
+        self._set_state(initial_state)
+        n = self.n_chains
+        self._n_reject = torch.zeros(n, dtype=torch.int64, device=self._tdev)
+        self._n_tries = torch.zeros(n, dtype=torch.int64, device=self._tdev)
+        self._err = torch.zeros(n, dtype=torch.int32, device=self._tdev)
+        self._tries_reported = 0
+
+    # ------------------------------------------------------------------ state handling
+    def _set_state(self, x):
+        if isinstance(x, torch.Tensor):
+            xt = x.detach().to(self._tdev, torch.float64)
+        else:
+            xt = torch.from_numpy(np.array(x, dtype=np.float64)).to(self._tdev)
+        self._single = xt.ndim == 1
+        if self._single:
+            xt = xt[None]
+        if xt.ndim != 2 or xt.shape[1] != self.target.d:
+            raise ValueError(f"initial_state must be (d,) or (n_chains, d) with d={self.target.d}")
+        xt = xt.contiguous()
+        n, d = xt.shape
+        self.n_chains, self.d = int(n), int(d)
+        self._state = torch.empty((d, n), dtype=torch.float64, device=self._tdev)  # component-major
+        _lib.check(self._lib.gsss_rows_to_components(xt.data_ptr(), self._state.data_ptr(), n, d, self.device,
+                                                     self._stream()))
+
+    def _stream(self):
+        return current_stream_ptr(self.device)
+
+    @property
+    def state_device(self):
+        """Component-major [d, n_chains] CUDA tensor holding the current states (no copy)."""
+        return self._state
+
+    def state_rows(self):
+        """Current states as an (n_chains, d) CUDA tensor."""
+        out = torch.empty((self.n_chains, self.d), dtype=torch.float64, device=self._tdev)
+        _lib.check(self._lib.gsss_components_to_rows(self._state.data_ptr(), out.data_ptr(), self.n_chains, self.d,
+                                                     self.device, self._stream()))
+        return out
+
+    @property
+    def state(self):
+        x = self.state_rows().cpu().numpy()
+        return x[0] if self._single else x
+
+    @state.setter
+    def state(self, value):
+        n_old = self.n_chains
+        self._set_state(value)
+        if self.n_chains != n_old:
+            raise ValueError("the number of chains is fixed at construction")
+
+    # ------------------------------------------------------------------ counters
+    @property
+    def n_reject_per_chain(self):
+        return self._n_reject.cpu().numpy()
+
+    @property
+    def n_tries_per_chain(self):
+        return self._n_tries.cpu().numpy()
+
+    @property
+    def n_reject(self):
+        """Total number of rejected proposals over all chains (mcmc.py:355, :374, :401)."""
+        return int(self._n_reject.sum().item())
+
+    @property
+    def errors(self):
+        """Per-chain GSSS_CHAIN_* bits (0 everywhere in a healthy run)."""
+        return self._err.cpu().numpy()
+
+    def _account_calls(self, n_steps):
+        """pdf.log_prob.num_calls protocol: one threshold evaluation per step plus one per try
+        (calls = steps + tries)."""
+        fn = getattr(type(self.target), "log_prob", None)
+        if fn is None or not hasattr(fn, "num_calls"):
+            return
+        tries = int(self._n_tries.sum().item())
+        fn.num_calls += n_steps * self.n_chains + (tries - self._tries_reported)
+        self._tries_reported = tries
+
+    def _check_errors(self):
+        bad = int((self._err != 0).sum().item())
+        if bad:
+            bits = int(self._err.max().item())
+            raise _lib.GsssError(f"{bad} chain(s) stopped with error bits (max {bits}): "
+                                 "1=max_tries, 2=non-finite log_prob, 4=replay exhausted")
+
+    # ------------------------------------------------------------------ running
+    def _launch(self, n_steps, samples=None, thin=1, replay=None):
+        a = _lib.RunArgs()
+        a.state_dev = self._state.data_ptr()
+        a.samples_dev = samples.data_ptr() if samples is not None else None
+        a.n_reject_dev = self._n_reject.data_ptr()
+        a.n_tries_dev = self._n_tries.data_ptr()
+        a.err_dev = self._err.data_ptr()
+        if replay is not None:
+            a.replay_dev = replay.data_ptr()
+            a.replay_stride = replay.shape[1]
+        a.n_chains = self.n_chains
+        a.n_steps = int(n_steps)
+        a.thin = int(thin)
+        a.seed = self.seed
+        a.chain_offset = self.chain_offset
+        a.step_offset = self._step
+        a.sampler = self._sampler
+        a.mode = _MODES[self.mode]
+        a.max_tries = min(self.max_tries, 2**31 - 1)
+        a.variant = self.variant
+        _lib.check(self._lib.gsss_run(self._target_dev.handle, C.byref(a), self._stream()))
+        self._step += int(n_steps)
+
+    def advance(self, n_steps, *, thin=None, out=None, replay=None):
+        """Advance every chain by n_steps transitions on the GPU (asynchronously).
+
+        thin=None keeps nothing; thin=t >= 1 keeps the state after every t-th step and returns a
+        CUDA tensor [n_steps // t, d, n_chains] (component-major, the kernels' native layout).
+        `replay` (n_chains, stride) replays recorded draws instead of the Philox stream.
+        """
+        n_steps = int(n_steps)
+        if n_steps < 0:
+            raise ValueError("n_steps must be >= 0")
+        if replay is not None:
+            if not isinstance(replay, torch.Tensor):
+                replay = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(replay), dtype=np.float64))
+            replay = replay.to(self._tdev, torch.float64).contiguous()
+            if replay.shape[0] != self.n_chains:
+                raise ValueError("replay needs one row per chain")
+        if thin is None:
+            done = 0
+            while done < n_steps:
+                m = n_steps - done if replay is not None else min(_MAX_STEPS_PER_LAUNCH, n_steps - done)
+                self._launch(m, replay=replay)
+                done += m
+            return None
+        thin = int(thin)
+        if thin < 1:
+            raise ValueError("thin must be >= 1")
+        n_keep = n_steps // thin
+        if out is None:
+            out = torch.empty((n_keep, self.d, self.n_chains), dtype=torch.float64, device=self._tdev)
+        elif tuple(out.shape) != (n_keep, self.d, self.n_chains) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 tensor [n_steps//thin, d, n_chains]")
+        if replay is not None:
+            self._launch(n_steps, samples=out, thin=thin, replay=replay)
+            return out
+        per = max(thin, (_MAX_STEPS_PER_LAUNCH // thin) * thin)
+        done = 0
+        while done < n_steps:
+            m = min(per, n_steps - done)
+            rows = m // thin
+            if rows:
+                r0 = done // thin
+                self._launch(m, samples=out[r0:r0 + rows], thin=thin)
+            else:
+                self._launch(m)
+            done += m
+        return out
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        """One transition of every chain; returns the new state(s) like the reference (mcmc.py:398-399)."""
+        self.advance(1)
+        self._account_calls(1)
+        self._check_errors()
+        return self.state
+
+    def sample(self, n_samples, burnin=0, return_all_samples=False, *, thin=1, as_tensor=False):
+        """Markov chain(s) of the desired size (mcmc.py:55-77): the initial state is row 0 of the
+        chain, `n_samples + burnin - 1` transitions are simulated, the first `burnin` rows are
+        dropped unless return_all_samples.  One chain -> (n_samples, d); many -> (n_chains, n_samples, d).
+
+        Extensions: thin=t keeps every t-th of the transitions after burn-in (row 0 stays the
+        post-burn-in state); as_tensor=True returns a CUDA tensor instead of a numpy array.
+        """
+        if not n_samples > 0:
+            raise AssertionError("n_samples must be positive")  # mcmc.py:62
+        burnin = determine_burnin(n_samples, burnin)
+        n_rows = n_samples + burnin if return_all_samples else n_samples
+        skip = 0 if return_all_samples else burnin
+        steps0 = self._step
+        if skip:
+            self.advance(skip)
+        rows = torch.empty((n_rows, self.d, self.n_chains), dtype=torch.float64, device=self._tdev)
+        rows[0].copy_(self._state)
+        if n_rows > 1:
+            self.advance((n_rows - 1) * thin, thin=thin, out=rows[1:])
+        out = torch.empty((self.n_chains, n_rows, self.d), dtype=torch.float64, device=self._tdev)
+        _lib.check(self._lib.gsss_samples_to_chains(rows.data_ptr(), out.data_ptr(), self.n_chains, n_rows, self.d,
+                                                    self.device, self._stream()))
+        self._account_calls(self._step - steps0)
+        self._check_errors()
+        if self._single:
+            out = out[0]
+        return out if as_tensor else out.cpu().numpy()
+
+
+class ShrinkageSphericalSliceSampler(RejectionSphericalSliceSampler):
+    """Geodesic shrinkage slice sampler (mcmc.py:377-401), many chains."""
+
+    _sampler = _lib.SHRINK

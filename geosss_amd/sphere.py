@@ -1,0 +1,41 @@
+"""Sphere helpers that sit on the sampler's path (geosss/sphere.py:10-50).
+
+The projections themselves run inside the HIP kernels; what is exposed here is the
+initial-state generator, the device twin of `sphere.sample_sphere`.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _device_index(device):
+    if device is None:
+        return int(torch.cuda.current_device()) if torch.cuda.is_available() else 0
+    if isinstance(device, torch.device):
+        return 0 if device.index is None else int(device.index)
+    return int(device)
+
+
+def current_stream_ptr(dev):
+    return int(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def sample_sphere_device(d, size, seed=0, chain_offset=0, device=None):
+    """`size` uniform points on S^d (d+1 ambient components, like geosss.sphere.sample_sphere,
+    sphere.py:39-50), generated on the GPU from the counter-based stream.  Returns a
+    COMPONENT-major torch tensor [d+1, size] (the layout the sampler keeps its states in)."""
+    _lib.require_device()
+    dev = _device_index(device)
+    out = torch.empty((d + 1, int(size)), dtype=torch.float64, device=f"cuda:{dev}")
+    _lib.check(_lib.load().gsss_sample_sphere(int(seed) & (2**64 - 1), int(chain_offset), int(size), d + 1,
+                                              out.data_ptr(), dev, current_stream_ptr(dev)))
+    return out
+
+
+def sample_sphere(d=2, size=None, seed=0, device=None):
+    """Same call signature as geosss.sphere.sample_sphere; rows are points.  Values come from
+    the library's Philox stream, not from numpy's PCG64."""
+    n = 1 if size is None else int(size)
+    x = sample_sphere_device(d, n, seed=seed, device=device).T.contiguous().cpu().numpy()
+    return x[0] if size is None else x

@@ -1,0 +1,50 @@
+"""Launcher + call counter with the reference's names (geosss/utils.py:137-232), restricted to
+the two samplers this package implements."""
+from .distributions import counted
+from .mcmc import RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler
+
+count_calls = counted
+
+
+def counter(method_names):
+    """Class decorator: wrap the named methods with the call counter (utils.py:162-185)."""
+    names = [method_names] if isinstance(method_names, str) else list(method_names)
+
+    def decorate(cls):
+        for name in names:
+            if hasattr(cls, name):
+                setattr(cls, name, counted(getattr(cls, name)))
+        return cls
+
+    return decorate
+
+
+class SamplerLauncher:
+    """`SamplerLauncher(pdf, initial, n_samples, burnin=0.2, seed=None).run("sss-shrink")`
+    (utils.py:188-232).  Keeps the sampler objects as `.ssss` / `.rsss` like the reference so
+    that callers can read `.n_reject` afterwards (scripts/curve_vMF.py:105-112)."""
+
+    def __init__(self, pdf, initial, n_samples, burnin=0.2, seed=None, **sampler_kwargs):
+        self.pdf = pdf
+        self.initial = initial
+        self.n_samples = n_samples
+        self.burnin = burnin
+        self.seed = seed
+        self.sampler_kwargs = sampler_kwargs
+
+    def run_sss_reject(self):
+        self.rsss = RejectionSphericalSliceSampler(self.pdf, self.initial, self.seed, **self.sampler_kwargs)
+        return self.rsss.sample(self.n_samples, burnin=self.burnin)
+
+    def run_sss_shrink(self):
+        self.ssss = ShrinkageSphericalSliceSampler(self.pdf, self.initial, self.seed, **self.sampler_kwargs)
+        return self.ssss.sample(self.n_samples, burnin=self.burnin)
+
+    def run(self, method):
+        if method == "sss-reject":
+            return self.run_sss_reject()
+        if method == "sss-shrink":
+            return self.run_sss_shrink()
+        if method in ("rwmh", "hmc"):
+            raise ValueError(f"method {method} is outside this package (only the geodesic slice samplers are built)")
+        raise ValueError(f"method {method} not known")

@@ -1,0 +1,163 @@
+/*
+ * gsss.h -- C ABI of libgsss_hip.so: many-chain geodesic slice sampling on the sphere,
+ * hand-written HIP for gfx950 (MI355X).
+ *
+ * The reference (microscopic-image-analysis/geosss) is pure Python and has no FFI for
+ * this path; its boundary is the duck-typed protocol
+ *     Sampler(distribution, initial_state, seed).sample(n_samples, burnin)
+ *     distribution.log_prob(x)
+ * (geosss/mcmc.py:28-77, 340-401; geosss/distributions.py:16-25).  The entry points
+ * below are what a ctypes binding of that protocol needs; each names the reference
+ * code it replaces.  INTEGRATION.md shows the binding a geosss maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative GSSS_E_* code and never throws;
+ *    gsss_last_error() gives the message of the calling thread's last failure.
+ *  - pointers named *_dev are DEVICE pointers on the target's device; the caller owns
+ *    every buffer, the library keeps none of them past the call (asynchronous work is
+ *    ordered on `stream`, so keep buffers alive until the stream has drained).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *    enqueue work; nothing synchronises except gsss_stream_synchronize/gsss_memcpy_*.
+ *  - all floating point is IEEE double, as in the reference.
+ *  - chain states are stored component-major ("SoA"): state_dev[j * n_chains + c] is
+ *    component j of chain c, so that one wavefront reads 64 consecutive doubles.
+ */
+#ifndef GSSS_H
+#define GSSS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSSS_ABI_VERSION 1
+
+/* target families (geosss/distributions.py) */
+#define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
+#define GSSS_BINGHAM 2     /* Bingham                         :36-103            */
+#define GSSS_CURVE_VMF 3   /* CurvedVonMisesFisher+SlerpCurve :261-278, spherical_curve.py:10-32,74-102 */
+
+/* samplers (geosss/mcmc.py) */
+#define GSSS_SHRINK 0 /* ShrinkageSphericalSliceSampler.__next__  :382-401 */
+#define GSSS_REJECT 1 /* RejectionSphericalSliceSampler.__next__  :357-374 */
+
+/* arithmetic of the proposal evaluation */
+#define GSSS_MODE_EXACT 0 /* y = cos*x + sin*u formed, log_prob(y) evaluated from y op by op as the reference does */
+#define GSSS_MODE_FAST 1  /* log_prob restricted to the great circle: O(1) per try after O(d) per step (same value to ~1e-14) */
+
+/* return codes */
+#define GSSS_OK 0
+#define GSSS_E_INVALID (-1)     /* bad argument */
+#define GSSS_E_UNSUPPORTED (-2) /* shape outside what the kernels cover */
+#define GSSS_E_HIP (-3)         /* a HIP runtime call failed */
+#define GSSS_E_NO_DEVICE (-4)   /* no usable gfx950 device */
+
+/* per-chain error bits written to gsss_run_args.err_dev */
+#define GSSS_CHAIN_MAX_TRIES 1        /* shrink/reject loop hit max_tries; state left at x */
+#define GSSS_CHAIN_NONFINITE 2        /* log_prob(state) was -inf/NaN (reference would spin forever, mcmc.py:394) */
+#define GSSS_CHAIN_REPLAY_EXHAUSTED 4 /* replay stream shorter than the draws consumed */
+
+typedef struct gsss_target gsss_target; /* opaque; owns a small device parameter block */
+
+/*
+ * Host-side description of a target.  All pointers are HOST pointers, copied at create.
+ *   VMF_MIXTURE: k components on S^{d-1}.  mu[k][d] = kappa_k * direction_k exactly as
+ *       VonMisesFisher stores it (distributions.py:126-127);  logc[k] = log(w_k) - log(2 pi)
+ *       - log(i0(|mu_k|)) = the x-independent part of distributions.py:157 and :220.
+ *   BINGHAM:     A[d][d] symmetric (distributions.py:67-70).
+ *   CURVE_VMF:   knots[k][d] unit vectors, kappa (distributions.py:263-265).
+ */
+typedef struct gsss_target_desc {
+    int32_t kind;
+    int32_t d;
+    int32_t k;
+    int32_t reserved;
+    const double *mu;
+    const double *logc;
+    const double *A;
+    const double *knots;
+    double kappa;
+} gsss_target_desc;
+
+/*
+ * One launch: advance n_chains chains by n_steps transitions each.
+ * Replaces the loop `while len(samples) < n: samples.append(next(self))` of Sampler.sample
+ * (mcmc.py:66-69) for all chains at once.
+ *
+ * Random numbers: counter-based Philox4x32-10 keyed by `seed`; the draws of chain c at
+ * step s are a pure function of (seed, chain_offset + c, step_offset + s), so any split of
+ * the chains over devices or of the steps over calls reproduces the same numbers
+ * (DESIGN.md "RNG stream").  If replay_dev is non-NULL the draws are read from it instead:
+ * per chain `replay_stride` doubles in the order the reference consumes them
+ * (d normals, u_threshold, [u_theta0,] u_try, u_try, ... ; next step ...) -- this is how the
+ * parity tests reproduce reference chains bit for bit.
+ */
+typedef struct gsss_run_args {
+    double *state_dev;         /* [d][n_chains] in/out                                             */
+    double *samples_dev;       /* [n_steps/thin][d][n_chains] or NULL; state after every thin-th step */
+    int64_t *n_reject_dev;     /* [n_chains] or NULL; rejections are ADDED (RejectionSphericalSliceSampler.n_reject) */
+    int64_t *n_tries_dev;      /* [n_chains] or NULL; log_prob(y) evaluations are ADDED            */
+    int32_t *err_dev;          /* [n_chains] or NULL; GSSS_CHAIN_* bits are OR-ed in               */
+    const double *replay_dev;  /* [n_chains][replay_stride] or NULL                                */
+    int64_t replay_stride;
+    int64_t n_chains;
+    int64_t n_steps;
+    int64_t thin;              /* >= 1 */
+    uint64_t seed;
+    uint64_t chain_offset;     /* global id of chain 0 of this call (< 2^48) */
+    uint64_t step_offset;      /* global id of step 0 of this call  (< 2^48 - 1) */
+    int32_t sampler;           /* GSSS_SHRINK | GSSS_REJECT */
+    int32_t mode;              /* GSSS_MODE_EXACT | GSSS_MODE_FAST */
+    int32_t max_tries;         /* > 0: give up a step after this many proposals */
+    int32_t variant;           /* 0 = library's choice; otherwise a kernel variant id (gsss_variant_name) */
+} gsss_run_args;
+
+int gsss_abi_version(void);
+const char *gsss_last_error(void);
+
+/* number of visible gfx950 devices (0 if none); does not fail */
+int gsss_device_count(void);
+
+/* distributions.py ctor twins: copy the parameters to `device` */
+int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **out);
+int gsss_target_destroy(gsss_target *t);
+int gsss_target_dim(const gsss_target *t);
+
+/* Distribution.log_prob for n points (distributions.py:84-86, :156-157, :218-221, :272-275).
+ * x_dev is ROW-major [n][d] (numpy's natural layout for pdf.log_prob(samples)). */
+int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *out_dev, void *stream);
+
+/* The sampler (see gsss_run_args). */
+int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);
+
+/* Names the kernel variant gsss_run would use / the variants available, for logs and benches. */
+const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t variant);
+
+/* sphere.sample_sphere twin (sphere.py:39-50): n uniform points on S^{d-1}, component-major,
+ * from the reserved step id of the RNG stream. */
+int gsss_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int32_t d, double *state_dev, int device,
+                       void *stream);
+
+/* Layout changes between numpy's row-major arrays and the component-major device layout.
+ *   gsss_rows_to_components: in [n][d]            -> out [d][n]
+ *   gsss_components_to_rows: in [d][n]            -> out [n][d]
+ *   gsss_samples_to_chains:  in [n_keep][d][n]    -> out [n][n_keep][d]   (chains, draws, dims) */
+int gsss_rows_to_components(const double *in_dev, double *out_dev, int64_t n, int32_t d, int device, void *stream);
+int gsss_components_to_rows(const double *in_dev, double *out_dev, int64_t n, int32_t d, int device, void *stream);
+int gsss_samples_to_chains(const double *in_dev, double *out_dev, int64_t n, int64_t n_keep, int32_t d, int device,
+                           void *stream);
+
+/* Minimal memory / stream helpers for callers without another HIP front-end (ctypes-only hosts). */
+int gsss_malloc(void **out_dev, size_t bytes, int device);
+int gsss_free(void *p_dev, int device);
+int gsss_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device, void *stream);
+int gsss_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream);
+int gsss_memset(void *dst_dev, int value, size_t bytes, int device, void *stream);
+int gsss_stream_synchronize(int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSSS_H */

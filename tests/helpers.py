@@ -1,0 +1,36 @@
+"""Shared helpers of the parity tests: build product-side targets from golden fixtures."""
+import numpy as np
+
+COOP_VARIANTS = {8: 16, 9: 32, 10: 64, 11: 128, 12: 256, 13: 512}  # variant id -> max d (gsss_launch.h)
+LANE_DIMS = {2: 1, 3: 2, 4: 3, 5: 4, 6: 5, 8: 6, 10: 7}            # d -> variant id
+
+
+def product_target(z, prefix="target_"):
+    import geosss_amd as gs
+    kind = str(z[prefix + "kind"])
+    if kind == "vmf_mixture":
+        return gs.MixtureModel([gs.VonMisesFisher(m) for m in z[prefix + "mu"]], z[prefix + "weights"])
+    if kind == "bingham":
+        return gs.Bingham(z[prefix + "A"])
+    if kind == "curve_vmf":
+        return gs.CurvedVonMisesFisher(gs.SlerpCurve(z[prefix + "knots"]), float(z[prefix + "kappa"]))
+    raise ValueError(kind)
+
+
+def variants_for(d, max_coop=2):
+    """Default variant (0) plus up to `max_coop` cooperative layouts that cover d."""
+    out = [0]
+    coop = [v for v, dmax in sorted(COOP_VARIANTS.items()) if d <= dmax]
+    if d not in LANE_DIMS and coop:
+        coop = coop[1:]  # the first one IS the default
+    return out + coop[:max_coop]
+
+
+def pad_replay(draws, offsets):
+    """Per-step rows of a recorded draw stream (teacher forcing)."""
+    n = len(offsets) - 1
+    width = int(np.max(np.diff(offsets)))
+    out = np.full((n, width), 0.5)
+    for i in range(n):
+        out[i, : offsets[i + 1] - offsets[i]] = draws[offsets[i]: offsets[i + 1]]
+    return out

@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden fixtures the
+reference produced and against the CPU oracle on the same seeded inputs.
+
+Tolerance: 1e-10 absolute on state components and relative-or-absolute on log-densities -- the
+bar BASELINE.json's north_star states; integer outputs (tries, rejections, error bits) exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, trajectory_names
+from helpers import pad_replay, product_target, variants_for
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def gs():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import geosss_amd
+    geosss_amd._lib.require_device()
+    return geosss_amd
+
+
+def _kat_cases():
+    z = golden("logprob_kat.npz")
+    return sorted({k.split("__")[0] for k in z.files})
+
+
+@pytest.mark.parametrize("name", _kat_cases())
+def test_logprob_kat(gs, name):
+    z = golden("logprob_kat.npz")
+    pdf = product_target(z, prefix=f"{name}__target_")
+    X, want = z[f"{name}__X"], z[f"{name}__logp"]
+    got = pdf.log_prob(X)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < TOL
+    one = pdf.log_prob(X[3])
+    assert isinstance(one, float) and abs(one - want[3]) / max(1.0, abs(want[3])) < TOL
+
+
+def _traj_params():
+    out = []
+    for name in trajectory_names("shrink") + trajectory_names("reject"):
+        d = int(golden(name + ".npz")["x0"].shape[0])
+        for v in variants_for(d):
+            out.append((name, v))
+    return out
+
+
+@pytest.mark.parametrize("name,variant", _traj_params())
+def test_trajectory_replay(gs, name, variant):
+    """Replaying the reference's recorded draws through the HIP kernel reproduces the
+    reference chain: every state (1e-10), tries per chain and n_reject (exact)."""
+    z = golden(name + ".npz")
+    pdf = product_target(z)
+    cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
+    s = cls(pdf, z["x0"], seed=1, variant=variant)
+    n = len(z["states"]) - 1
+    kept = s.advance(n, thin=1, replay=z["draws"][None])
+    got = kept[:, :, 0].cpu().numpy()
+    assert s.errors[0] == 0
+    assert np.max(np.abs(got - z["states"][1:])) < TOL
+    assert s.n_reject == int(z["n_reject"])
+    assert int(s.n_tries_per_chain[0]) == int(z["tries"].sum())
+    assert np.max(np.abs(s.state - z["states"][-1])) < TOL
+
+
+@pytest.mark.parametrize("name", trajectory_names("shrink"))
+def test_trajectory_teacher_forced(gs, name):
+    """All steps of the reference chain at once: chain i starts from reference state i and
+    replays the draws of step i; compares the next state and the number of tries."""
+    z = golden(name + ".npz")
+    pdf = product_target(z)
+    states = z["states"]
+    s = gs.ShrinkageSphericalSliceSampler(pdf, states[:-1], seed=1)
+    s.advance(1, replay=pad_replay(z["draws"], z["step_draw_offset"]))
+    assert np.all(s.errors == 0)
+    assert np.max(np.abs(s.state - states[1:])) < TOL
+    assert np.array_equal(s.n_tries_per_chain, z["tries"])
+
+
+ORACLE_CASES = [("vmfmix_readme", 512, 60), ("vmfmix_k10_kappa500", 256, 40), ("vmfmix_d10_k5_kappa100", 256, 40),
+                ("bingham_d10_vmax30", 256, 40), ("bingham_d5_dense", 256, 40), ("bingham_d50_vmax300", 96, 25),
+                ("curve_d10_kappa800", 128, 30), ("curve_d24_kappa800", 64, 20), ("curve_d50_kappa800", 64, 20),
+                ("curve_d200_kappa800", 48, 12)]
+
+
+@pytest.mark.parametrize("name,n_chains,n_steps", ORACLE_CASES)
+@pytest.mark.parametrize("sampler", ["shrink", "reject"])
+def test_philox_stream_matches_oracle(gs, oracle, name, n_chains, n_steps, sampler):
+    """Same seed, same chain ids -> the device's Philox-driven chains equal the oracle's:
+    states within 1e-10 after every step, tries / rejections exactly."""
+    if sampler == "reject" and not name.startswith(("vmfmix_readme", "bingham_d10")):
+        pytest.skip("rejection sampler covered on two targets")
+    z = golden(f"traj_{name}.npz")
+    pdf, tgt = product_target(z), oracle.Target.from_fixture(z)
+    d = len(z["x0"])
+    x0 = oracle.sample_sphere(11, n_chains, d, chain_offset=1000)
+    kind = oracle.REJECT if sampler == "reject" else oracle.SHRINK
+    want = oracle.run(tgt, x0, n_steps, seed=2024, chain_offset=1000, step_offset=7, sampler=kind, n_threads=8)
+    cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    s = cls(pdf, x0, seed=2024, chain_offset=1000, step_offset=7)
+    kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()  # (chains, steps, d)
+    assert np.all(s.errors == 0) and np.all(want["err"] == 0)
+    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    assert np.array_equal(s.n_reject_per_chain, want["n_reject"])
+    assert np.max(np.abs(kept - want["samples"])) < TOL
+
+
+def test_sample_sphere_matches_oracle(gs, oracle):
+    for d in (3, 10, 51):
+        got = gs.sample_sphere_device(d - 1, 1000, seed=99, chain_offset=5).T.cpu().numpy()
+        want = oracle.sample_sphere(99, 1000, d, chain_offset=5)
+        assert np.max(np.abs(got - want)) < 1e-13
+        assert np.max(np.abs(np.linalg.norm(got, axis=1) - 1)) < 1e-14
+    x = gs.sample_sphere(2, 7, seed=3)
+    assert x.shape == (7, 3)
+    assert gs.sample_sphere(2, seed=3).shape == (3,)
+
+
+def test_partition_and_resume_invariance(gs):
+    """Chains split over two 'ranks' (chain_offset) and steps split over two calls give the
+    same bits as one run -- what makes the multi-GPU sharding exact."""
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere(2, 4096, seed=5)
+    full = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=42)
+    a = full.advance(30, thin=1).cpu().numpy()
+    lo = gs.ShrinkageSphericalSliceSampler(pdf, x0[:1500], seed=42, chain_offset=0)
+    hi = gs.ShrinkageSphericalSliceSampler(pdf, x0[1500:], seed=42, chain_offset=1500)
+    b = np.concatenate([lo.advance(30, thin=1).cpu().numpy(), hi.advance(30, thin=1).cpu().numpy()], axis=2)
+    assert np.array_equal(a, b)
+    two = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=42)
+    two.advance(13)
+    two.advance(17)
+    assert np.array_equal(two.state, full.state)
+    assert np.array_equal(two.n_reject_per_chain, full.n_reject_per_chain)
+    # cooperative layout computes the same chains (bitwise is not required, 1e-10 is)
+    coop = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=42, variant=8)
+    c = coop.advance(30, thin=1).cpu().numpy()
+    assert np.max(np.abs(a - c)) < TOL
+    assert np.array_equal(coop.n_reject_per_chain, full.n_reject_per_chain)
+
+
+def test_sample_api_semantics(gs):
+    """README.md:44-64 call shape: sample(1000, 100) -> (1000, 3); row bookkeeping of
+    mcmc.py:55-77; n_reject and log_prob.num_calls bookkeeping."""
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    type(pdf).log_prob.reset_counters()
+    x0 = z["x0"]
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, 3521)
+    out = s.sample(1000, 100)
+    assert out.shape == (1000, 3) and out.dtype == np.float64
+    assert s._step == 1099
+    assert pdf.log_prob.num_calls == 1099 + int(s.n_tries_per_chain.sum())
+    assert s.n_reject == int(s.n_tries_per_chain.sum()) - 1099
+    assert np.array_equal(out[-1], s.state)
+    # the same chain again, all rows: row 0 is the initial state, rows [100:] are the call above
+    s2 = gs.ShrinkageSphericalSliceSampler(pdf, x0, 3521)
+    allrows = s2.sample(1000, 100, return_all_samples=True)
+    assert allrows.shape == (1100, 3)
+    assert np.array_equal(allrows[0], x0)
+    assert np.array_equal(allrows[100:], out)
+    # many chains: (chains, draws, dims); float burnin = fraction
+    x0n = gs.sample_sphere(2, 300, seed=1)
+    s3 = gs.ShrinkageSphericalSliceSampler(pdf, x0n, 7)
+    o3 = s3.sample(50, burnin=0.2)
+    assert o3.shape == (300, 50, 3) and s3._step == 59
+    s4 = gs.ShrinkageSphericalSliceSampler(pdf, x0n, 7)
+    o4 = s4.sample(60, burnin=0, return_all_samples=True)
+    assert np.array_equal(o4[:, 0], x0n) and np.array_equal(o4[:, 10:], o3)
+    # iterator protocol
+    s5 = gs.ShrinkageSphericalSliceSampler(pdf, x0n, 7)
+    y = next(s5)
+    assert y.shape == (300, 3) and np.array_equal(y, o4[:, 1])
+    # thinning keeps every t-th transition
+    s6 = gs.ShrinkageSphericalSliceSampler(pdf, x0n, 7)
+    o6 = s6.sample(20, thin=3)
+    assert np.array_equal(o6, o4[:, 0:58:3])
+    # launcher
+    L = gs.SamplerLauncher(pdf, x0n, 50, burnin=0.2, seed=7)
+    assert np.array_equal(L.run("sss-shrink"), o3) and L.ssss.n_reject == s3.n_reject
+    with pytest.raises(ValueError):
+        L.run("nope")
+
+
+def test_error_reporting(gs):
+    from geosss_amd._lib import GsssError
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere(2, 128, seed=1)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, max_tries=1)
+    s.advance(5)
+    assert np.any(s.errors & 1) and np.all((s.errors & ~1) == 0)
+    with pytest.raises(GsssError):
+        s._check_errors()
+    # replay stream too short -> flagged, not read out of bounds
+    s = gs.ShrinkageSphericalSliceSampler(pdf, z["x0"], 1)
+    s.advance(50, replay=z["draws"][None, :40])
+    assert s.errors[0] & 4
+    # NaN state -> non-finite log_prob -> flagged instead of spinning forever
+    bad = np.array(x0)
+    bad[3] = np.nan
+    s = gs.ShrinkageSphericalSliceSampler(pdf, bad, 1)
+    s.advance(3)
+    e = s.errors
+    assert e[3] & 2 and np.all(np.delete(e, 3) == 0)
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, np.zeros(4), 1)
+    with pytest.raises(ValueError):
+        pdf.log_prob(np.zeros((5, 4)))
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, mode="fast").advance(1)
+
+
+def test_layout_round_trip(gs):
+    import torch
+    lib = gs._lib.load()
+    for n, d in ((1, 3), (1000, 3), (777, 10), (65, 200)):
+        x = torch.randn(n, d, dtype=torch.float64, device="cuda")
+        c = torch.empty(d, n, dtype=torch.float64, device="cuda")
+        r = torch.empty(n, d, dtype=torch.float64, device="cuda")
+        gs._lib.check(lib.gsss_rows_to_components(x.data_ptr(), c.data_ptr(), n, d, 0, None))
+        gs._lib.check(lib.gsss_components_to_rows(c.data_ptr(), r.data_ptr(), n, d, 0, None))
+        torch.cuda.synchronize()
+        assert torch.equal(c, x.T.contiguous()) and torch.equal(r, x)
+    s = torch.randn(7, 3, 130, dtype=torch.float64, device="cuda")
+    o = torch.empty(130, 7, 3, dtype=torch.float64, device="cuda")
+    gs._lib.check(lib.gsss_samples_to_chains(s.data_ptr(), o.data_ptr(), 130, 7, 3, 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(o, s.permute(2, 0, 1).contiguous())
