@@ -286,14 +286,13 @@ struct VmfMixture {
 
 template <class V>
 struct Bingham {
-    const double *A;  // LDS [DPAD][DPAD], zero padded
-    __host__ __device__ static size_t lds_doubles(int /*k*/, int /*d*/) { return (size_t)V::DPAD * V::DPAD; }
+    const double *A;  // LDS [d][DPAD]: rows of A, columns zero padded
+    int d;
+    __host__ __device__ static size_t lds_doubles(int /*k*/, int d) { return (size_t)d * V::DPAD; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
-        for (int i = threadIdx.x; i < V::DPAD * V::DPAD; i += kBlock) {
-            const int r = i / V::DPAD, c = i - r * V::DPAD;
-            lds[i] = (r < tb.d && c < tb.d) ? tb.blob[(size_t)r * tb.d + c] : 0.0;
-        }
+        d = tb.d;
+        lds_fill(lds, tb.d, V::DPAD, tb.blob, tb.d);
         A = lds;
     }
     // sum_j (sum_i y_i A_ij) y_j
@@ -319,7 +318,7 @@ struct Bingham {
             double xa[V::N];
 #pragma unroll
             for (int j = 0; j < V::N; ++j) xa[j] = 0.0;
-            for (int i = 0; i < V::DPAD; ++i) {
+            for (int i = 0; i < d; ++i) {
                 const double yi = scratch[i];
 #pragma unroll
                 for (int j = 0; j < V::N; ++j) xa[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], xa[j]);
