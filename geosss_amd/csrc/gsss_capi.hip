@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "gsss_fast.h"
 #include "gsss_launch.h"
 
 namespace gsss {
@@ -154,6 +155,17 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
 }
 
 }  // namespace gsss
+
+static int fast_dispatch(const gsss::TargetBlock &tb, const gsss::RunBlock &rb, bool replay, bool probe,
+                         hipStream_t st)
+{
+    switch (tb.kind) {
+    case GSSS_VMF_MIXTURE: return gsss::launch_fast_vmf(tb, rb, replay, probe, st);
+    case GSSS_BINGHAM: return gsss::launch_fast_bingham(tb, rb, replay, probe, st);
+    }
+    if (!probe) gsss::set_error("fast mode is not built for target kind %d", tb.kind);
+    return GSSS_E_UNSUPPORTED;
+}
 
 // ==========================================================================================
 // extern "C"
@@ -317,9 +329,9 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("unknown sampler %d", a->sampler);
         return GSSS_E_INVALID;
     }
-    if (a->mode != GSSS_MODE_EXACT) {
-        set_error("mode %d is not built into this library", a->mode);
-        return GSSS_E_UNSUPPORTED;
+    if (a->mode != GSSS_MODE_EXACT && a->mode != GSSS_MODE_FAST) {
+        set_error("unknown mode %d", a->mode);
+        return GSSS_E_INVALID;
     }
     if (a->chain_offset + (uint64_t)a->n_chains > (1ull << 48) || a->step_offset + (uint64_t)a->n_steps >= kInitStep) {
         set_error("chain / step ids exceed the 48-bit counter space");
@@ -334,7 +346,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("replay_stride must be >= 1");
         return GSSS_E_INVALID;
     }
-    const int vec = select_vec(t->tb.d, a->variant);
+    const int vec = a->mode == GSSS_MODE_FAST ? 0 : select_vec(t->tb.d, a->variant);
     if (vec < 0) return vec;
     RunBlock rb;
     rb.state = a->state_dev;
@@ -356,6 +368,13 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool replay = a->replay_dev != nullptr;
+    if (a->mode == GSSS_MODE_FAST) {
+        if (a->n_steps > 0x7FFFFFFFll || a->thin > 0x7FFFFFFFll) {
+            set_error("fast mode takes at most 2^31-1 steps per call");
+            return GSSS_E_INVALID;
+        }
+        return fast_dispatch(t->tb, rb, replay, false, st);
+    }
     switch (t->tb.kind) {
     case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, replay, t->tb, rb, st);
     case GSSS_BINGHAM: return launch_run<Bingham>(vec, replay, t->tb, rb, st);
@@ -365,9 +384,18 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     return GSSS_E_INVALID;
 }
 
-const char *gsss_variant_name(const gsss_target *t, int32_t /*mode*/, int32_t variant)
+int gsss_mode_supported(const gsss_target *t, int32_t mode)
+{
+    if (!t) return 0;
+    if (mode == GSSS_MODE_EXACT) return select_vec(t->tb.d, 0) >= 0;
+    if (mode == GSSS_MODE_FAST) return fast_dispatch(t->tb, RunBlock{}, false, true, nullptr) == GSSS_OK;
+    return 0;
+}
+
+const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t variant)
 {
     if (!t) return "";
+    if (mode == GSSS_MODE_FAST) return gsss_mode_supported(t, mode) ? "fast-lane-2chain" : "";
     const int vec = select_vec(t->tb.d, variant);
     if (vec < 0) return "";
     int n;

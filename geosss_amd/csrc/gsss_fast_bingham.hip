@@ -1,0 +1,21 @@
+// GSSS_MODE_FAST instantiations for Bingham targets.
+#include "gsss_fast.h"
+
+namespace gsss {
+
+#define GSSS_FAST_BINGHAM_DIMS(X) X(3) X(4) X(5) X(10)
+
+int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
+{
+#define GSSS_CASE(D)                                               \
+    if (tb.d == D) {                                               \
+        if (probe) return GSSS_OK;                                 \
+        return do_fast<D, FastBingham<D>>(tb, rb, replay, st);     \
+    }
+    GSSS_FAST_BINGHAM_DIMS(GSSS_CASE)
+#undef GSSS_CASE
+    if (!probe) set_error("fast mode is not built for a Bingham target with d=%d", tb.d);
+    return GSSS_E_UNSUPPORTED;
+}
+
+}  // namespace gsss

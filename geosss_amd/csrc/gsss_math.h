@@ -1,0 +1,102 @@
+// gsss_math.h -- double-precision elementary functions specialised for the sampler's hot loop.
+//
+// The generic device-library sincos/exp carry large-argument reduction and double-double
+// corrections the shrinkage loop never needs: theta always lies in [-2 pi, 2 pi] and the
+// exponents are differences of log-densities.  These versions are ~1 ulp accurate on their
+// stated domains (tests/test_math.py measures them against libm on the host build) and cost
+// a third of the instructions.  Everything is plain FMA arithmetic, identical on host and device.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GSSS_HD __host__ __device__ __forceinline__
+#else
+#define GSSS_HD inline
+#endif
+
+namespace gsss {
+namespace fm {
+
+// sin / cos kernels on |r| <= pi/4 (classic fdlibm minimax polynomials, |err| < 2^-57)
+GSSS_HD double sin_kernel(double r)
+{
+    const double z = r * r;
+    double p = 1.58969099521155010221e-10;
+    p = fma(p, z, -2.50507602534068634195e-08);
+    p = fma(p, z, 2.75573137070700676789e-06);
+    p = fma(p, z, -1.98412698298579493134e-04);
+    p = fma(p, z, 8.33333333332248946124e-03);
+    p = fma(p, z, -1.66666666666666324348e-01);
+    return fma(r * z, p, r);
+}
+
+GSSS_HD double cos_kernel(double r)
+{
+    const double z = r * r;
+    double p = -1.13596475577881948265e-11;
+    p = fma(p, z, 2.08757232129817482790e-09);
+    p = fma(p, z, -2.75573143513906633035e-07);
+    p = fma(p, z, 2.48015872894767294178e-05);
+    p = fma(p, z, -1.38888888888741095749e-03);
+    p = fma(p, z, 4.16666666666666019037e-02);
+    // 1 - z/2 + z^2 p, with the 1 - z/2 rounding error folded back in
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + z * z * p);
+}
+
+GSSS_HD void quadrant_select(int q, double s, double c, double &so, double &co)
+{
+    const bool swap = q & 1;
+    const double a = swap ? c : s;
+    const double b = swap ? s : c;
+    so = (q & 2) ? -a : a;
+    co = ((q + 1) & 2) ? -b : b;
+}
+
+// sin and cos of x for |x| <= 8 (three-bit quadrant index, two-term Cody-Waite reduction)
+GSSS_HD void sincos_small(double x, double &so, double &co)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);  // 2/pi
+    double r = fma(-k, 1.57079632673412561417e+00, x);       // pi/2 high 33 bits: k * it is exact
+    r = fma(-k, 6.07710050650619224932e-11, r);              // pi/2 - high part
+    quadrant_select((int)k & 3, sin_kernel(r), cos_kernel(r), so, co);
+}
+
+// sin and cos of 2 pi u for u in [0, 1): exact octant reduction in units of turns
+GSSS_HD void sincos_2pi(double u, double &so, double &co)
+{
+    const double t = 4.0 * u;
+    const double k = rint(t);
+    const double r = (t - k) * 1.57079632679489661923;  // (t - k) is exact
+    quadrant_select((int)k & 3, sin_kernel(r), cos_kernel(r), so, co);
+}
+
+// exp(x) for any finite x (and -inf): n = round(x / ln 2), degree-13 Taylor on |r| <= ln2/2
+// (truncation 4e-18), scaled by 2^n with ldexp (gradual underflow, overflow to +inf)
+GSSS_HD double exp_fast(double x)
+{
+    const double xc = fmin(fmax(x, -800.0), 800.0);
+    const double n = rint(xc * 1.44269504088896338700e+00);
+    double r = fma(-n, 6.93147180369123816490e-01, xc);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;       // 1/13!
+    p = fma(p, r, 2.08767569878680989792e-09);  // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);  // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);  // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);  // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);  // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);  // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);  // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);  // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);  // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);  // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return x == x ? ldexp(p, (int)n) : x;  // NaN stays NaN
+}
+
+}  // namespace fm
+}  // namespace gsss

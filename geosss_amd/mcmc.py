@@ -27,7 +27,7 @@ from .sphere import _device_index, current_stream_ptr
 
 __all__ = ["determine_burnin", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler"]
 
-_MODES = {"exact": _lib.MODE_EXACT, "fast": _lib.MODE_FAST}
+_MODES = {"exact": _lib.MODE_EXACT, "fast": _lib.MODE_FAST, "auto": None}
 _MAX_STEPS_PER_LAUNCH = 4096
 
 
@@ -68,7 +68,7 @@ class RejectionSphericalSliceSampler:
 
     _sampler = _lib.REJECT
 
-    def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="exact", max_tries=None,
+    def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="auto", max_tries=None,
                  chain_offset=0, step_offset=0, variant=0):
         _lib.require_device()
         self._lib = _lib.load()
@@ -85,6 +85,9 @@ class RejectionSphericalSliceSampler:
         self.variant = int(variant)
         self._step = int(step_offset)
         self._target_dev = distribution._device_target(self.device)
+        if mode == "auto":  # the throughput kernels where they are built for this shape, else the generic ones
+            fast_ok = self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST) and not variant
+            self.mode = "fast" if fast_ok else "exact"
         self._set_state(initial_state)
         n = self.n_chains
         self._n_reject = torch.zeros(n, dtype=torch.int64, device=self._tdev)

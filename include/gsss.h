@@ -132,6 +132,10 @@ int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *o
 /* The sampler (see gsss_run_args). */
 int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);
 
+/* 1 if gsss_run accepts `mode` for this target's shape (fast mode is built for the shapes listed in
+ * geosss_amd/csrc/gsss_fast_*.hip), else 0. */
+int gsss_mode_supported(const gsss_target *t, int32_t mode);
+
 /* Names the kernel variant gsss_run would use / the variants available, for logs and benches. */
 const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t variant);
 

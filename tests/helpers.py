@@ -34,3 +34,22 @@ def pad_replay(draws, offsets):
     for i in range(n):
         out[i, : offsets[i + 1] - offsets[i]] = draws[offsets[i]: offsets[i + 1]]
     return out
+
+
+# shapes the GSSS_MODE_FAST kernels are built for (geosss_amd/csrc/gsss_fast_*.hip)
+FAST_VMF = {(3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 10), (4, 4), (10, 5)}
+FAST_BINGHAM = {3, 4, 5, 10}
+
+
+def fast_supported(z, prefix="target_"):
+    kind = str(z[prefix + "kind"])
+    if kind == "vmf_mixture":
+        k, d = z[prefix + "mu"].shape
+        return (d, k) in FAST_VMF
+    if kind == "bingham":
+        return z[prefix + "A"].shape[0] in FAST_BINGHAM
+    return False
+
+
+def modes_for(z):
+    return ["exact", "fast"] if fast_supported(z) else ["exact"]

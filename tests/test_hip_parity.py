@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, trajectory_names
-from helpers import pad_replay, product_target, variants_for
+from helpers import modes_for, pad_replay, product_target, variants_for
 
 pytestmark = pytest.mark.gpu
 
@@ -45,19 +45,23 @@ def _traj_params():
     out = []
     for name in trajectory_names("shrink") + trajectory_names("reject"):
         d = int(golden(name + ".npz")["x0"].shape[0])
+        z = golden(name + ".npz")
         for v in variants_for(d):
-            out.append((name, v))
+            out.append((name, v, "exact"))
+        if "fast" in modes_for(z):
+            out.append((name, 0, "fast"))
     return out
 
 
-@pytest.mark.parametrize("name,variant", _traj_params())
-def test_trajectory_replay(gs, name, variant):
+@pytest.mark.parametrize("name,variant,mode", _traj_params())
+def test_trajectory_replay(gs, name, variant, mode):
     """Replaying the reference's recorded draws through the HIP kernel reproduces the
     reference chain: every state (1e-10), tries per chain and n_reject (exact)."""
     z = golden(name + ".npz")
     pdf = product_target(z)
     cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
-    s = cls(pdf, z["x0"], seed=1, variant=variant)
+    s = cls(pdf, z["x0"], seed=1, variant=variant, mode=mode)
+    assert s.mode == mode
     n = len(z["states"]) - 1
     kept = s.advance(n, thin=1, replay=z["draws"][None])
     got = kept[:, :, 0].cpu().numpy()
@@ -68,14 +72,18 @@ def test_trajectory_replay(gs, name, variant):
     assert np.max(np.abs(s.state - z["states"][-1])) < TOL
 
 
-@pytest.mark.parametrize("name", trajectory_names("shrink"))
-def test_trajectory_teacher_forced(gs, name):
+def _tf_params():
+    return [(n, m) for n in trajectory_names("shrink") for m in modes_for(golden(n + ".npz"))]
+
+
+@pytest.mark.parametrize("name,mode", _tf_params())
+def test_trajectory_teacher_forced(gs, name, mode):
     """All steps of the reference chain at once: chain i starts from reference state i and
     replays the draws of step i; compares the next state and the number of tries."""
     z = golden(name + ".npz")
     pdf = product_target(z)
     states = z["states"]
-    s = gs.ShrinkageSphericalSliceSampler(pdf, states[:-1], seed=1)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, states[:-1], seed=1, mode=mode)
     s.advance(1, replay=pad_replay(z["draws"], z["step_draw_offset"]))
     assert np.all(s.errors == 0)
     assert np.max(np.abs(s.state - states[1:])) < TOL
@@ -90,19 +98,24 @@ ORACLE_CASES = [("vmfmix_readme", 512, 60), ("vmfmix_k10_kappa500", 256, 40), ("
 
 @pytest.mark.parametrize("name,n_chains,n_steps", ORACLE_CASES)
 @pytest.mark.parametrize("sampler", ["shrink", "reject"])
-def test_philox_stream_matches_oracle(gs, oracle, name, n_chains, n_steps, sampler):
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_philox_stream_matches_oracle(gs, oracle, name, n_chains, n_steps, sampler, mode):
     """Same seed, same chain ids -> the device's Philox-driven chains equal the oracle's:
     states within 1e-10 after every step, tries / rejections exactly."""
     if sampler == "reject" and not name.startswith(("vmfmix_readme", "bingham_d10")):
         pytest.skip("rejection sampler covered on two targets")
     z = golden(f"traj_{name}.npz")
+    if mode not in modes_for(z):
+        pytest.skip("fast mode is not built for this shape")
+    if mode == "fast":
+        n_chains, n_steps = 4 * n_chains + 77, 2 * n_steps  # ragged tail block, longer chains
     pdf, tgt = product_target(z), oracle.Target.from_fixture(z)
     d = len(z["x0"])
     x0 = oracle.sample_sphere(11, n_chains, d, chain_offset=1000)
     kind = oracle.REJECT if sampler == "reject" else oracle.SHRINK
     want = oracle.run(tgt, x0, n_steps, seed=2024, chain_offset=1000, step_offset=7, sampler=kind, n_threads=8)
     cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
-    s = cls(pdf, x0, seed=2024, chain_offset=1000, step_offset=7)
+    s = cls(pdf, x0, seed=2024, chain_offset=1000, step_offset=7, mode=mode)
     kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()  # (chains, steps, d)
     assert np.all(s.errors == 0) and np.all(want["err"] == 0)
     assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
@@ -213,8 +226,9 @@ def test_error_reporting(gs):
         gs.ShrinkageSphericalSliceSampler(pdf, np.zeros(4), 1)
     with pytest.raises(ValueError):
         pdf.log_prob(np.zeros((5, 4)))
-    with pytest.raises(ValueError):
-        gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, mode="fast").advance(1)
+    zc = golden("traj_curve_d24_kappa800.npz")
+    with pytest.raises(ValueError):  # fast mode is not built for this shape: refused, no silent fallback
+        gs.ShrinkageSphericalSliceSampler(product_target(zc), zc["x0"], 1, mode="fast").advance(1)
 
 
 def test_layout_round_trip(gs):

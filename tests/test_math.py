@@ -1,0 +1,76 @@
+"""Accuracy of the sampler's own elementary functions (geosss_amd/csrc/gsss_math.h), measured
+on a host build of the same header against numpy/libm.  The functions are pure FMA arithmetic, so
+the device evaluates the same operations (the GPU parity tests cover the device side end to end)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+SRC = os.path.join(ROOT, "tests", "cpp", "math_host.cpp")
+HDR = os.path.join(ROOT, "geosss_amd", "csrc", "gsss_math.h")
+OUT = os.path.join(ROOT, "tests", "_build", "libmath_host.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
+                               "-o", OUT, SRC])
+    return C.CDLL(OUT)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ulps(got, want):
+    return np.abs(got - want) / np.spacing(np.abs(want))
+
+
+def test_sincos_small(lib):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-2 * np.pi, 2 * np.pi, 400000), np.linspace(-8, 8, 100001),
+                        np.array([0.0, np.pi / 4, -np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, -2 * np.pi, 1e-300, 1e-9])])
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib.t_sincos_small(_p(x), C.c_long(len(x)), _p(s), _p(c))
+    xl = x.astype(np.longdouble)
+    ws, wc = np.sin(xl).astype(np.float64), np.cos(xl).astype(np.float64)
+    # absolute error near zeros of sin/cos is what matters for y = cos*x + sin*u
+    assert np.max(np.abs(s - ws)) < 2.5e-16 and np.max(np.abs(c - wc)) < 2.5e-16
+    big = np.abs(ws) > 0.1
+    assert np.max(ulps(s[big], ws[big])) <= 2.0
+    big = np.abs(wc) > 0.1
+    assert np.max(ulps(c[big], wc[big])) <= 2.0
+
+
+def test_sincos_2pi(lib):
+    rng = np.random.default_rng(2)
+    u = np.concatenate([rng.random(400000), np.array([0.0, 0.125, 0.25, 0.5, 0.75, 1 - 2.0**-53])])
+    s, c = np.empty_like(u), np.empty_like(u)
+    lib.t_sincos_2pi(_p(u), C.c_long(len(u)), _p(s), _p(c))
+    a = 2 * np.longdouble("3.14159265358979323846264338327950288") * u.astype(np.longdouble)
+    assert np.max(np.abs(s - np.sin(a).astype(np.float64))) < 2.5e-16
+    assert np.max(np.abs(c - np.cos(a).astype(np.float64))) < 2.5e-16
+    assert s[-6] == 0.0 and c[-6] == 1.0  # u = 0
+
+
+def test_exp(lib):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-745, 709, 400000), rng.uniform(-5, 5, 200000), np.linspace(-1, 1, 20001),
+                        np.array([0.0, -0.0, 1.0, -1.0, 709.7, -744.0])])
+    y = np.empty_like(x)
+    lib.t_exp(_p(x), C.c_long(len(x)), _p(y))
+    want = np.exp(x.astype(np.longdouble)).astype(np.float64)
+    normal = want > 1e-300
+    assert np.max(ulps(y[normal], want[normal])) <= 1.5
+    tiny = ~normal  # near / below the normal range: 1 ulp of a subnormal is coarse, allow it
+    assert np.all(np.abs(y[tiny] - want[tiny]) <= np.maximum(4e-16 * want[tiny], 1e-323))
+    e = np.array([-np.inf, np.inf, -1e4, 1e4, np.nan])
+    y = np.empty_like(e)
+    lib.t_exp(_p(e), C.c_long(len(e)), _p(y))
+    assert y[0] == 0.0 and y[1] == np.inf and y[2] == 0.0 and y[3] == np.inf and np.isnan(y[4])
