@@ -139,15 +139,15 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
     dr.init(rb, c, d);
     dr.begin_step(kInitStep);
     double ss = 0.0;
-    for (int j = 0; 2 * j < d; ++j) {
-        double u0, u1, z0, z1;
-        dr.block(1u + (uint32_t)j, u0, u1);
-        box_muller(u0, u1, z0, z1);
-        out[(size_t)(2 * j) * n + c] = z0;
-        ss = fma(z0, z0, ss);
-        if (2 * j + 1 < d) {
-            out[(size_t)(2 * j + 1) * n + c] = z1;
-            ss = fma(z1, z1, ss);
+    for (int q = 0; 4 * q < d; ++q) {
+        uint32_t w[4];
+        double zz[4];
+        dr.words(1u + (uint32_t)q, w);
+        box_muller32(w[0], w[1], zz[0], zz[1]);
+        box_muller32(w[2], w[3], zz[2], zz[3]);
+        for (int i = 0; i < 4 && 4 * q + i < d; ++i) {
+            out[(size_t)(4 * q + i) * n + c] = zz[i];
+            ss = fma(zz[i], zz[i], ss);
         }
     }
     const double nrm = sqrt(ss) + 1e-100;  // sphere.py:14
@@ -369,8 +369,9 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool replay = a->replay_dev != nullptr;
     if (a->mode == GSSS_MODE_FAST) {
-        if (a->n_steps > 0x7FFFFFFFll || a->thin > 0x7FFFFFFFll) {
-            set_error("fast mode takes at most 2^31-1 steps per call");
+        if (a->n_steps > 0x7FFFFFFFll || a->thin > 0x7FFFFFFFll || a->n_chains > 0x7FFFFFFFll - 1024 ||
+            a->replay_stride > 0x7FFFFFFFll) {
+            set_error("fast mode takes at most 2^31-1 steps / chains per call");
             return GSSS_E_INVALID;
         }
         return fast_dispatch(t->tb, rb, replay, false, st);

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/gsss.h"
+#include "gsss_math.h"
 
 namespace gsss {
 
@@ -68,12 +69,12 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * 0x1.0p-53;
 }
 
-// Box-Muller pair from two uniforms of one stream block
-__device__ __forceinline__ void box_muller(double u0, double u1, double &z0, double &z1)
+// Box-Muller pair from two 32-bit words of a stream block: radius word -> (0,1], angle word -> [0,1)
+__device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, double &z0, double &z1)
 {
-    const double r = sqrt(-2.0 * log(1.0 - u0));
+    const double r = sqrt(-2.0 * fm::log_fast(((double)wr + 1.0) * 0x1.0p-32));
     double s, c;
-    sincospi(2.0 * u1, &s, &c);
+    fm::sincos_2pi((double)wa * 0x1.0p-32, s, c);
     z0 = r * c;
     z1 = r * s;
 }
@@ -84,7 +85,7 @@ constexpr uint64_t kInitStep = 0xFFFFFFFFFFFFull;  // reserved step id: initial 
 // Vector policies: how the d components of one chain map onto lanes.
 //   LaneVec<D>   : one lane per chain, all D components in that lane's registers.
 //   CoopVec<L,S> : L lanes per chain (L | 64), S register slots per lane, components dealt in
-//                  pairs (2p, 2p+1), pair p = g + L*ip, so each lane owns whole Box-Muller pairs.
+//                  quads (4q .. 4q+3), quad q = g + L*iq, so each lane owns whole RNG blocks.
 // Slots beyond d hold zeros (and zero-padded parameters), so dots need no guards.
 // ------------------------------------------------------------------------------------------
 template <int D_>
@@ -99,12 +100,12 @@ struct LaneVec {
 
 template <int L_, int S_>
 struct CoopVec {
-    static_assert(S_ % 2 == 0, "slots come in pairs");
+    static_assert(S_ % 4 == 0, "slots come in quads");
     static constexpr int L = L_;
     static constexpr int N = S_;
     static constexpr int DPAD = L_ * S_;
     static constexpr bool kExactDim = false;  // any d <= DPAD
-    __device__ static __forceinline__ int comp(int g, int i) { return 2 * (g + L_ * (i >> 1)) + (i & 1); }
+    __device__ static __forceinline__ int comp(int g, int i) { return 4 * (g + L_ * (i >> 2)) + (i & 3); }
     // xor-butterfly over the L lanes of a group: every lane ends with the same bits
     __device__ static __forceinline__ double reduce(double v)
     {
@@ -150,26 +151,33 @@ struct PhiloxDraws {
         c3 = chain_hi | ((uint32_t)((step >> 32) & 0xFFFFu) << 16);
         t = 0;
     }
+    __device__ __forceinline__ void words(uint32_t blk, uint32_t (&w)[4]) const
+    {
+        philox4x32_10(blk, c1, c2, c3, k0, k1, w);
+    }
     __device__ __forceinline__ void block(uint32_t blk, double &u0, double &u1) const
     {
         uint32_t w[4];
-        philox4x32_10(blk, c1, c2, c3, k0, k1, w);
+        words(blk, w);
         u0 = u53(w[0], w[1]);
         u1 = u53(w[2], w[3]);
     }
+    // block 1+q carries the normals 4q .. 4q+3
     __device__ __forceinline__ void normals(double (&z)[V::N], int g) const
     {
 #pragma unroll
-        for (int ip = 0; ip < (V::N + 1) / 2; ++ip) {
-            const int c0 = V::comp(g, 2 * ip);
-            double z0 = 0.0, z1 = 0.0;
+        for (int iq = 0; iq < (V::N + 3) / 4; ++iq) {
+            const int c0 = V::comp(g, 4 * iq);
+            double zz[4] = {0.0, 0.0, 0.0, 0.0};
             if (c0 < d) {
-                double u0, u1;
-                block(1u + (uint32_t)(c0 >> 1), u0, u1);
-                box_muller(u0, u1, z0, z1);
+                uint32_t w[4];
+                words(1u + (uint32_t)(c0 >> 2), w);
+                box_muller32(w[0], w[1], zz[0], zz[1]);
+                if (c0 + 2 < d) box_muller32(w[2], w[3], zz[2], zz[3]);
             }
-            z[2 * ip] = z0;
-            if (2 * ip + 1 < V::N) z[2 * ip + 1] = (c0 + 1 < d) ? z1 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * iq + i < V::N) z[4 * iq + i] = (c0 + i < d) ? zz[i] : 0.0;
         }
     }
     __device__ __forceinline__ void step_uniforms(double &u_thr, double &u_theta0, bool /*need_theta0*/) const
@@ -181,7 +189,7 @@ struct PhiloxDraws {
         const int tt = t++;
         if (tt & 1) return cached;
         double u0;
-        block(1u + (uint32_t)((d + 1) >> 1) + (uint32_t)(tt >> 1), u0, cached);
+        block(1u + (uint32_t)((d + 3) >> 2) + (uint32_t)(tt >> 1), u0, cached);
         return u0;
     }
 };

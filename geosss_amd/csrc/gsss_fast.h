@@ -33,29 +33,31 @@ enum : int32_t { kReady = 0, kPending = 1, kDone = 2 };
 
 // ------------------------------------------------------------------------------------------
 // restricted targets (lane layout, D components in registers)
+//   make(cf, x, u, lvl, fresh)  coefficients of the circle through x along u; returns the level
+//                               of x (theta = 0).  `lvl` is the level the accepting try computed
+//                               for this very point: targets reuse it unless `fresh`.
+//   level(cf, c, s)             level of y(theta); accept iff level > threshold
+//   kLinear                     level is a density (threshold = level(x) * U) rather than a
+//                               log-density (threshold = level(x) + log U)
 // ------------------------------------------------------------------------------------------
 template <int D, int KC>
 struct FastVmf {
     static constexpr bool kLinear = true;
-    static constexpr int kKind = GSSS_VMF_MIXTURE;
     const double *mu;    // LDS [KC][D]
     const double *logc;  // LDS [KC]
     struct Coef {
         double ax[KC], bu[KC], m;
     };
     __host__ __device__ static size_t lds_doubles() { return (size_t)KC * D + KC; }
-    __host__ static bool covers(int d, int k) { return d == D && k == KC; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         for (int i = threadIdx.x; i < KC * D + KC; i += kBlock) lds[i] = tb.blob[i];
         mu = lds;
         logc = lds + KC * D;
     }
-    // coefficients of the circle through x along u; returns sum_k e^{a_k(x) - m}
-    __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D]) const
+    __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D], double lvl,
+                                           bool fresh) const
     {
-        double a0[KC];
-        double m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             double ax = 0.0, bu = 0.0;
@@ -67,14 +69,19 @@ struct FastVmf {
             }
             cf.ax[k] = ax;
             cf.bu[k] = bu;
-            a0[k] = ax + logc[k];
-            m = fmax(m, a0[k]);
         }
-        cf.m = m;
-        double s = 0.0;
+        // the offset m only keeps the exponentials in range; re-centre it when the carried level
+        // has drifted far from 1 (or on the first step of a launch)
+        if (fresh || !(lvl > 1e-150 && lvl < 1e150)) {
+            double m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < KC; ++k) s += fm::exp_fast(a0[k] - m);
-        return s;
+            for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + logc[k]);
+            cf.m = m;
+            lvl = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) lvl += fm::exp_fast((cf.ax[k] + logc[k]) - m);
+        }
+        return lvl;
     }
     __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
     {
@@ -88,19 +95,18 @@ struct FastVmf {
 template <int D>
 struct FastBingham {
     static constexpr bool kLinear = false;
-    static constexpr int kKind = GSSS_BINGHAM;
     const double *A;  // LDS [D][D]
     struct Coef {
         double qxx, qxu, quu;
     };
     __host__ __device__ static size_t lds_doubles() { return (size_t)D * D; }
-    __host__ static bool covers(int d, int /*k*/) { return d == D; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         for (int i = threadIdx.x; i < D * D; i += kBlock) lds[i] = tb.blob[i];
         A = lds;
     }
-    __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D]) const
+    __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D], double /*lvl*/,
+                                           bool /*fresh*/) const
     {
         double qxx = 0.0, qxu = 0.0, quu = 0.0;
 #pragma unroll
@@ -128,57 +134,91 @@ struct FastBingham {
 };
 
 // ------------------------------------------------------------------------------------------
-// per-chain registers
+// per-chain registers: only what must survive between tries.  RNG counters are rebuilt from
+// (id, steps_done, t) when a draw is needed.
 // ------------------------------------------------------------------------------------------
-template <int D, class TP, class Dr>
+template <int D, class TP>
 struct FastChain {
     double x[D], u[D];
     typename TP::Coef cf;
-    double lo, hi, thr;
-    Dr dr;
-    int64_t id;       // chain index within this call (addressing); < 0: no chain
-    int64_t n_try, n_rej;
-    int32_t steps_done, steps_left;
+    double lo, hi, thr, lvl;
+    int64_t n_try;
+    int32_t id;          // chain index within this call; < 0: no chain
+    int32_t steps_done;
     int32_t until_keep, row;
+    int32_t t;           // proposals made in the current step
     int32_t status, err;
-    int32_t t;        // proposals made in the current step
+    int32_t cursor;      // replay: draws consumed
 };
 
-template <int D, class TP, template <class> class DR>
+template <int D, class TP, bool REPLAY>
 __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
-    using Dr = DR<V>;
-    using Chain = FastChain<D, TP, Dr>;
+    using Chain = FastChain<D, TP>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
     __syncthreads();
 
-    const int64_t n = a.n_chains;
+    const int32_t n = (int32_t)a.n_chains;
+    const int32_t n_steps = (int32_t)a.n_steps;
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int32_t thin = (int32_t)a.thin;
+    constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
 
-    auto init = [&](Chain &ch, int64_t c) {
+    auto philox = [&](const Chain &ch) {
+        PhiloxDraws<V> dr;
+        dr.init(a, ch.id, D);
+        dr.begin_step(a.step_offset + (uint64_t)ch.steps_done);
+        return dr;
+    };
+    auto replay_take = [&](Chain &ch) -> double {
+        if (ch.cursor >= (int32_t)a.replay_stride) {
+            ch.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            return 0.5;
+        }
+        return a.replay[(size_t)ch.id * a.replay_stride + ch.cursor++];
+    };
+
+    auto init = [&](Chain &ch, int32_t c) {
         const bool valid = c < n;
         ch.id = valid ? c : -1;
-        const int64_t cc = valid ? c : 0;
+        const int32_t cc = valid ? c : 0;
 #pragma unroll
         for (int j = 0; j < D; ++j) ch.x[j] = a.state[(size_t)j * n + cc];
-        ch.dr.init(a, cc, D);
-        ch.n_try = ch.n_rej = 0;
+        ch.n_try = 0;
         ch.steps_done = 0;
-        ch.steps_left = valid ? (int32_t)a.n_steps : 0;
         ch.until_keep = thin;
         ch.row = 0;
         ch.err = 0;
-        ch.status = ch.steps_left > 0 ? kPending : kDone;
+        ch.cursor = 0;
+        ch.lvl = 0.0;
+        ch.t = 0;
+        ch.status = (valid && n_steps > 0) ? kPending : kDone;
     };
 
     // everything a step needs before its first try (mcmc.py:387-392)
     auto setup = [&](Chain &ch) {
-        ch.dr.begin_step(a.step_offset + (uint64_t)ch.steps_done);
-        ch.dr.normals(ch.u, 0);
+        double u_thr, u_th0;
+        if (REPLAY) {
+            if (ch.cursor + D <= (int32_t)a.replay_stride) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) ch.u[j] = a.replay[(size_t)ch.id * a.replay_stride + ch.cursor + j];
+                ch.cursor += D;
+            } else {
+#pragma unroll
+                for (int j = 0; j < D; ++j) ch.u[j] = 0.5;
+                ch.cursor = (int32_t)a.replay_stride;
+                ch.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            }
+            u_thr = replay_take(ch);
+            u_th0 = shrink ? replay_take(ch) : 0.0;
+        } else {
+            const PhiloxDraws<V> dr = philox(ch);
+            dr.normals(ch.u, 0);
+            dr.block(0u, u_thr, u_th0);
+        }
         {  // u = spherical_projection(z, x), sphere.py:29-33, with reciprocals instead of divisions
             const double rnx = 1.0 / (sqrt(vdot<V>(ch.x, ch.x)) + 1e-100);
             double cz = 0.0;
@@ -190,15 +230,13 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
 #pragma unroll
             for (int j = 0; j < D; ++j) ch.u[j] *= rnw;
         }
-        double u_thr, u_th0;
-        ch.dr.step_uniforms(u_thr, u_th0, shrink);
-        const double lvl0 = tp.make(ch.cf, ch.x, ch.u);
+        const double lvl0 = tp.make(ch.cf, ch.x, ch.u, ch.lvl, ch.steps_done == 0);
         bool finite;
         if (TP::kLinear) {
             ch.thr = lvl0 * u_thr;
             finite = lvl0 > 0.0 && lvl0 < INFINITY;
         } else {
-            ch.thr = lvl0 + log(u_thr);
+            ch.thr = lvl0 + fm::log_fast(u_thr);
             finite = lvl0 > -INFINITY && lvl0 < INFINITY;
         }
         if (shrink) {
@@ -216,50 +254,51 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         }
     };
 
+    // up to two proposals (one Philox block feeds both: the stream hands tries out in pairs)
     auto attempt = [&](Chain &ch) {
         if (ch.t >= a.max_tries) {
             ch.n_try += ch.t;
-            ch.n_rej += ch.t;
             ch.err |= GSSS_CHAIN_MAX_TRIES;
             ch.status = kDone;
             return;
         }
-        const double theta = fma(ch.hi - ch.lo, ch.dr.next_try(), ch.lo);  // mcmc.py:395
-        ++ch.t;
-        double sn, cs;
-        fm::sincos_small(theta, sn, cs);
-        const double lvl = tp.level(ch.cf, cs, sn);
-        const bool exhausted = Dr::kReplay && ch.dr.exhausted;
-        if (lvl > ch.thr) {                                                  // mcmc.py:397
+        double u_pair[2];
+        if (!REPLAY) philox(ch).block(kTryBase + (uint32_t)(ch.t >> 1), u_pair[0], u_pair[1]);
+        bool accepted = false;
+        double sn = 0.0, cs = 1.0, lvl = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!accepted && (h == 0 || ch.t < a.max_tries) && !(REPLAY && (ch.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
+                const double uu = REPLAY ? replay_take(ch) : u_pair[h];
+                const double theta = fma(ch.hi - ch.lo, uu, ch.lo);  // mcmc.py:395
+                ++ch.t;
+                fm::sincos_small(theta, sn, cs);
+                lvl = tp.level(ch.cf, cs, sn);
+                accepted = lvl > ch.thr;                              // mcmc.py:397
+                if (!accepted && shrink) {                            // mcmc.py:400
+                    if (theta < 0.0)
+                        ch.lo = theta;
+                    else
+                        ch.hi = theta;
+                }
+            }
+        }
+        const bool exhausted = REPLAY && (ch.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
+        if (accepted) {
 #pragma unroll
             for (int j = 0; j < D; ++j) ch.x[j] = fma(sn, ch.u[j], cs * ch.x[j]);  // mcmc.py:396
+            ch.lvl = lvl;
             ch.n_try += ch.t;
-            ch.n_rej += exhausted ? ch.t : ch.t - 1;
             ++ch.steps_done;
-            --ch.steps_left;
             if (a.samples != nullptr && --ch.until_keep == 0) {
                 ch.until_keep = thin;
 #pragma unroll
                 for (int j = 0; j < D; ++j) a.samples[((size_t)ch.row * D + j) * n + ch.id] = ch.x[j];
                 ++ch.row;
             }
-            ch.status = ch.steps_left > 0 ? kPending : kDone;
-            if (exhausted) {
-                ch.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
-                ch.status = kDone;
-            }
-            return;
-        }
-        if (shrink) {                                                        // mcmc.py:400
-            if (theta < 0.0)
-                ch.lo = theta;
-            else
-                ch.hi = theta;
-        }
-        if (exhausted) {
+            ch.status = (ch.steps_done < n_steps && !exhausted) ? kPending : kDone;
+        } else if (exhausted) {
             ch.n_try += ch.t;
-            ch.n_rej += ch.t;
-            ch.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
             ch.status = kDone;
         }
     };
@@ -271,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     };
 
     Chain cur, oth;
-    const int64_t base = (int64_t)blockIdx.x * kFastChainsPerBlock + threadIdx.x;
+    const int32_t base = (int32_t)blockIdx.x * kFastChainsPerBlock + (int32_t)threadIdx.x;
     init(cur, base);
     init(oth, base + kBlock);
     if (cur.status == kPending) setup(cur);
@@ -299,7 +338,9 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         if (ch.id < 0) return;
 #pragma unroll
         for (int j = 0; j < D; ++j) a.state[(size_t)j * n + ch.id] = ch.x[j];
-        if (a.n_reject) a.n_reject[ch.id] += ch.n_rej;
+        // every accepted step has exactly one non-rejected proposal (counters of a chain that
+        // stopped with an error bit are not specified beyond that bit)
+        if (a.n_reject) a.n_reject[ch.id] += ch.n_try - ch.steps_done;
         if (a.n_tries) a.n_tries[ch.id] += ch.n_try;
         if (a.err && ch.err) a.err[ch.id] |= ch.err;
     };
@@ -310,11 +351,11 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
 // host side: launch one instantiation
 void set_error(const char *fmt, ...);
 
-template <int D, class TP, template <class> class DR>
+template <int D, class TP, bool REPLAY>
 int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
     const size_t lds = TP::lds_doubles() * sizeof(double);
-    auto kern = fast_kernel<D, TP, DR>;
+    auto kern = fast_kernel<D, TP, REPLAY>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -336,7 +377,7 @@ int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 template <int D, class TP>
 int do_fast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
 {
-    return replay ? do_fast_run<D, TP, ReplayDraws>(tb, rb, st) : do_fast_run<D, TP, PhiloxDraws>(tb, rb, st);
+    return replay ? do_fast_run<D, TP, true>(tb, rb, st) : do_fast_run<D, TP, false>(tb, rb, st);
 }
 
 // per-target entry points (one translation unit each); GSSS_E_UNSUPPORTED when no instantiation

@@ -98,5 +98,28 @@ GSSS_HD double exp_fast(double x)
     return x == x ? ldexp(p, (int)n) : x;  // NaN stays NaN
 }
 
+// log(x) for finite normal x > 0 (fdlibm's s = f/(2+f) series, |err| < 1 ulp); x = 0 -> -inf
+GSSS_HD double log_fast(double x)
+{
+    if (!(x > 0.0)) return x == 0.0 ? -INFINITY : NAN;
+    int e;
+    double m = frexp(x, &e);  // m in [0.5, 1)
+    if (m < 7.07106781186547524401e-01) {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double f = m - 1.0;  // [-0.2929, 0.4142]
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 }  // namespace fm
 }  // namespace gsss

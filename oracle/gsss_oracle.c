@@ -232,10 +232,10 @@ static double gor_u53(uint32_t a, uint32_t b)
     return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-/* block `blk` of (seed, chain, step): two uniforms */
-void gor_stream_block(uint64_t seed, uint64_t chain, uint64_t step, uint32_t blk, double u[2])
+/* block `blk` of (seed, chain, step): four 32-bit words */
+void gor_stream_words(uint64_t seed, uint64_t chain, uint64_t step, uint32_t blk, uint32_t w[4])
 {
-    uint32_t ctr[4], key[2], w[4];
+    uint32_t ctr[4], key[2];
     ctr[0] = blk;
     ctr[1] = (uint32_t)step;
     ctr[2] = (uint32_t)chain;
@@ -243,8 +243,24 @@ void gor_stream_block(uint64_t seed, uint64_t chain, uint64_t step, uint32_t blk
     key[0] = (uint32_t)seed;
     key[1] = (uint32_t)(seed >> 32);
     gor_philox4x32_10(ctr, key, w);
+}
+
+/* ... read as two 53-bit uniforms */
+void gor_stream_block(uint64_t seed, uint64_t chain, uint64_t step, uint32_t blk, double u[2])
+{
+    uint32_t w[4];
+    gor_stream_words(seed, chain, step, blk, w);
     u[0] = gor_u53(w[0], w[1]);
     u[1] = gor_u53(w[2], w[3]);
+}
+
+/* ... or as two Box-Muller pairs from four 32-bit uniforms (radius word in (0,1], angle word in [0,1)) */
+static void gor_box_muller32(uint32_t wr, uint32_t wa, double *z0, double *z1)
+{
+    double r = sqrt(-2.0 * log(((double)wr + 1.0) * (1.0 / 4294967296.0)));
+    double ang = 6.283185307179586 * ((double)wa * (1.0 / 4294967296.0));
+    *z0 = r * cos(ang);
+    *z1 = r * sin(ang);
 }
 
 typedef struct {
@@ -276,13 +292,13 @@ static void gor_draw_normals(gor_draws *g, double *z)
         for (int i = 0; i < d; ++i) z[i] = gor_take(g);
         return;
     }
-    for (int j = 0; 2 * j < d; ++j) {
-        double u[2];
-        gor_stream_block(g->seed, g->chain, g->step, (uint32_t)(1 + j), u);
-        double r = sqrt(-2.0 * log(1.0 - u[0]));
-        double ang = 6.283185307179586 * u[1];
-        z[2 * j] = r * cos(ang);
-        if (2 * j + 1 < d) z[2 * j + 1] = r * sin(ang);
+    for (int j = 0; 4 * j < d; ++j) { /* block 1+j carries normals 4j .. 4j+3 */
+        uint32_t w[4];
+        double zz[4];
+        gor_stream_words(g->seed, g->chain, g->step, (uint32_t)(1 + j), w);
+        gor_box_muller32(w[0], w[1], &zz[0], &zz[1]);
+        gor_box_muller32(w[2], w[3], &zz[2], &zz[3]);
+        for (int i = 0; i < 4 && 4 * j + i < d; ++i) z[4 * j + i] = zz[i];
     }
 }
 
@@ -307,7 +323,7 @@ static double gor_draw_try(gor_draws *g)
     int64_t t = g->try_idx++;
     if (t & 1) return g->cached;
     double u[2];
-    uint32_t nb = (uint32_t)((g->d + 1) / 2);
+    uint32_t nb = (uint32_t)((g->d + 3) / 4);
     gor_stream_block(g->seed, g->chain, g->step, 1u + nb + (uint32_t)(t >> 1), u);
     g->cached = u[1];
     return u[0];

@@ -74,3 +74,19 @@ def test_exp(lib):
     y = np.empty_like(e)
     lib.t_exp(_p(e), C.c_long(len(e)), _p(y))
     assert y[0] == 0.0 and y[1] == np.inf and y[2] == 0.0 and y[3] == np.inf and np.isnan(y[4])
+
+
+def test_log(lib):
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.random(400000), (rng.integers(0, 2**32, 200000) + 1.0) / 2.0**32,
+                        np.exp(rng.uniform(-700, 700, 100000)), np.array([1.0, 0.5, 2.0, 2.0**-32, 1 - 2.0**-53])])
+    y = np.empty_like(x)
+    lib.t_log(_p(x), C.c_long(len(x)), _p(y))
+    want = np.log(x.astype(np.longdouble)).astype(np.float64)
+    nz = want != 0
+    assert np.max(ulps(y[nz], want[nz])) <= 1.5
+    assert np.all(y[~nz] == 0.0)
+    e = np.array([0.0, -1.0, np.nan])
+    y = np.empty_like(e)
+    lib.t_log(_p(e), C.c_long(len(e)), _p(y))
+    assert y[0] == -np.inf and np.isnan(y[1]) and np.isnan(y[2])
