@@ -47,7 +47,17 @@ struct FastVmf {
     const double *logc;  // LDS [KC]
     struct Coef {
         double ax[KC], bu[KC], m;
+        template <class F>
+        __device__ __forceinline__ void each(F &&f)
+        {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) f(ax[k]);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) f(bu[k]);
+            f(m);
+        }
     };
+    static constexpr int kCoefWords = 2 * KC + 1;
     __host__ __device__ static size_t lds_doubles() { return (size_t)KC * D + KC; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
@@ -98,7 +108,15 @@ struct FastBingham {
     const double *A;  // LDS [D][D]
     struct Coef {
         double qxx, qxu, quu;
+        template <class F>
+        __device__ __forceinline__ void each(F &&f)
+        {
+            f(qxx);
+            f(qxu);
+            f(quu);
+        }
     };
+    static constexpr int kCoefWords = 3;
     __host__ __device__ static size_t lds_doubles() { return (size_t)D * D; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
@@ -134,8 +152,9 @@ struct FastBingham {
 };
 
 // ------------------------------------------------------------------------------------------
-// per-chain registers: only what must survive between tries.  RNG counters are rebuilt from
-// (id, steps_done, t) when a draw is needed.
+// per-chain state: only what must survive between tries.  RNG counters are rebuilt from
+// (id, steps_done, t) when a draw is needed.  A lane keeps its current chain in registers and
+// its other chain in an LDS slot; the two trade places with one ds_wrxchg per 64-bit word.
 // ------------------------------------------------------------------------------------------
 template <int D, class TP>
 struct FastChain {
@@ -143,13 +162,36 @@ struct FastChain {
     typename TP::Coef cf;
     double lo, hi, thr, lvl;
     int64_t n_try;
-    int32_t id;          // chain index within this call; < 0: no chain
-    int32_t steps_done;
-    int32_t until_keep, row;
-    int32_t t;           // proposals made in the current step
+    int32_t steps_done, until_keep;
+    int32_t row, t;      // t = proposals made in the current step
     int32_t status, err;
-    int32_t cursor;      // replay: draws consumed
+    int32_t cursor, pad; // replay: draws consumed
+    static constexpr int kWords = 2 * D + TP::kCoefWords + 4 + 1 + 3 + 1;
 };
+
+__device__ __forceinline__ void lds_trade(double &v, unsigned long long *slot)
+{
+    const unsigned long long o = __hip_atomic_exchange(slot, (unsigned long long)__double_as_longlong(v),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    v = __longlong_as_double((long long)o);
+}
+__device__ __forceinline__ void lds_trade(int64_t &v, unsigned long long *slot)
+{
+    v = (int64_t)__hip_atomic_exchange(slot, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_trade(int32_t &a, int32_t &b, unsigned long long *slot)
+{
+    const unsigned long long mine = (unsigned long long)(uint32_t)a | ((unsigned long long)(uint32_t)b << 32);
+    const unsigned long long o = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    a = (int32_t)(uint32_t)o;
+    b = (int32_t)(uint32_t)(o >> 32);
+}
+
+template <int D, class TP>
+__host__ __device__ constexpr size_t fast_lds_doubles()
+{
+    return TP::lds_doubles() + (size_t)FastChain<D, TP>::kWords * kBlock;
+}
 
 template <int D, class TP, bool REPLAY>
 __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a)
@@ -159,6 +201,8 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
+    // word w of this lane's parked chain lives at park[w * kBlock]: conflict-free across lanes
+    unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles()) + threadIdx.x;
     __syncthreads();
 
     const int32_t n = (int32_t)a.n_chains;
@@ -166,186 +210,251 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int32_t thin = (int32_t)a.thin;
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
+    const int32_t base = (int32_t)blockIdx.x * kFastChainsPerBlock + (int32_t)threadIdx.x;
 
-    auto philox = [&](const Chain &ch) {
+    Chain cur;
+    int32_t slot = 0;               // which of the lane's two chains `cur` is: id = base + slot * kBlock
+    int32_t parked_status = kDone;  // status of the chain in LDS
+
+    auto chain_id = [&]() { return base + slot * kBlock; };
+    auto philox = [&]() {
         PhiloxDraws<V> dr;
-        dr.init(a, ch.id, D);
-        dr.begin_step(a.step_offset + (uint64_t)ch.steps_done);
+        dr.init(a, chain_id(), D);
+        dr.begin_step(a.step_offset + (uint64_t)cur.steps_done);
         return dr;
     };
-    auto replay_take = [&](Chain &ch) -> double {
-        if (ch.cursor >= (int32_t)a.replay_stride) {
-            ch.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+    auto replay_take = [&]() -> double {
+        if (cur.cursor >= (int32_t)a.replay_stride) {
+            cur.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
             return 0.5;
         }
-        return a.replay[(size_t)ch.id * a.replay_stride + ch.cursor++];
+        return a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor++];
     };
 
-    auto init = [&](Chain &ch, int32_t c) {
+    auto init = [&]() {
+        const int32_t c = chain_id();
         const bool valid = c < n;
-        ch.id = valid ? c : -1;
         const int32_t cc = valid ? c : 0;
 #pragma unroll
-        for (int j = 0; j < D; ++j) ch.x[j] = a.state[(size_t)j * n + cc];
-        ch.n_try = 0;
-        ch.steps_done = 0;
-        ch.until_keep = thin;
-        ch.row = 0;
-        ch.err = 0;
-        ch.cursor = 0;
-        ch.lvl = 0.0;
-        ch.t = 0;
-        ch.status = (valid && n_steps > 0) ? kPending : kDone;
+        for (int j = 0; j < D; ++j) cur.x[j] = a.state[(size_t)j * n + cc];
+        cur.n_try = 0;
+        cur.steps_done = 0;
+        cur.until_keep = thin;
+        cur.row = 0;
+        cur.err = 0;
+        cur.cursor = 0;
+        cur.pad = 0;
+        cur.lvl = 0.0;
+        cur.t = 0;
+        cur.status = (valid && n_steps > 0) ? kPending : kDone;
     };
 
     // everything a step needs before its first try (mcmc.py:387-392)
-    auto setup = [&](Chain &ch) {
+    auto setup = [&]() {
         double u_thr, u_th0;
         if (REPLAY) {
-            if (ch.cursor + D <= (int32_t)a.replay_stride) {
+            if (cur.cursor + D <= (int32_t)a.replay_stride) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) ch.u[j] = a.replay[(size_t)ch.id * a.replay_stride + ch.cursor + j];
-                ch.cursor += D;
+                for (int j = 0; j < D; ++j)
+                    cur.u[j] = a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor + j];
+                cur.cursor += D;
             } else {
 #pragma unroll
-                for (int j = 0; j < D; ++j) ch.u[j] = 0.5;
-                ch.cursor = (int32_t)a.replay_stride;
-                ch.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+                for (int j = 0; j < D; ++j) cur.u[j] = 0.5;
+                cur.cursor = (int32_t)a.replay_stride;
+                cur.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
             }
-            u_thr = replay_take(ch);
-            u_th0 = shrink ? replay_take(ch) : 0.0;
+            u_thr = replay_take();
+            u_th0 = shrink ? replay_take() : 0.0;
         } else {
-            const PhiloxDraws<V> dr = philox(ch);
-            dr.normals(ch.u, 0);
+            const PhiloxDraws<V> dr = philox();
+            dr.normals(cur.u, 0);
             dr.block(0u, u_thr, u_th0);
         }
         {  // u = spherical_projection(z, x), sphere.py:29-33, with reciprocals instead of divisions
-            const double rnx = 1.0 / (sqrt(vdot<V>(ch.x, ch.x)) + 1e-100);
+            const double rnx = 1.0 / (sqrt(vdot<V>(cur.x, cur.x)) + 1e-100);
             double cz = 0.0;
 #pragma unroll
-            for (int j = 0; j < D; ++j) cz = fma(ch.u[j], ch.x[j] * rnx, cz);
+            for (int j = 0; j < D; ++j) cz = fma(cur.u[j], cur.x[j] * rnx, cz);
 #pragma unroll
-            for (int j = 0; j < D; ++j) ch.u[j] = fma(-cz, ch.x[j] * rnx, ch.u[j]);
-            const double rnw = 1.0 / (sqrt(vdot<V>(ch.u, ch.u)) + 1e-100);
+            for (int j = 0; j < D; ++j) cur.u[j] = fma(-cz, cur.x[j] * rnx, cur.u[j]);
+            const double rnw = 1.0 / (sqrt(vdot<V>(cur.u, cur.u)) + 1e-100);
 #pragma unroll
-            for (int j = 0; j < D; ++j) ch.u[j] *= rnw;
+            for (int j = 0; j < D; ++j) cur.u[j] *= rnw;
         }
-        const double lvl0 = tp.make(ch.cf, ch.x, ch.u, ch.lvl, ch.steps_done == 0);
+        const double lvl0 = tp.make(cur.cf, cur.x, cur.u, cur.lvl, cur.steps_done == 0);
         bool finite;
         if (TP::kLinear) {
-            ch.thr = lvl0 * u_thr;
+            cur.thr = lvl0 * u_thr;
             finite = lvl0 > 0.0 && lvl0 < INFINITY;
         } else {
-            ch.thr = lvl0 + fm::log_fast(u_thr);
+            cur.thr = lvl0 + fm::log_fast(u_thr);
             finite = lvl0 > -INFINITY && lvl0 < INFINITY;
         }
         if (shrink) {
-            ch.hi = kTwoPi * u_th0;
-            ch.lo = ch.hi - kTwoPi;
+            cur.hi = kTwoPi * u_th0;
+            cur.lo = cur.hi - kTwoPi;
         } else {
-            ch.lo = 0.0;
-            ch.hi = kTwoPi;
+            cur.lo = 0.0;
+            cur.hi = kTwoPi;
         }
-        ch.t = 0;
-        ch.status = kReady;
+        cur.t = 0;
+        cur.status = kReady;
         if (!finite) {
-            ch.err |= GSSS_CHAIN_NONFINITE;
-            ch.status = kDone;
+            cur.err |= GSSS_CHAIN_NONFINITE;
+            cur.status = kDone;
         }
     };
 
     // up to two proposals (one Philox block feeds both: the stream hands tries out in pairs)
-    auto attempt = [&](Chain &ch) {
-        if (ch.t >= a.max_tries) {
-            ch.n_try += ch.t;
-            ch.err |= GSSS_CHAIN_MAX_TRIES;
-            ch.status = kDone;
+    auto attempt = [&]() {
+        if (cur.t >= a.max_tries) {
+            cur.n_try += cur.t;
+            cur.err |= GSSS_CHAIN_MAX_TRIES;
+            cur.status = kDone;
             return;
         }
         double u_pair[2];
-        if (!REPLAY) philox(ch).block(kTryBase + (uint32_t)(ch.t >> 1), u_pair[0], u_pair[1]);
+        if (!REPLAY) philox().block(kTryBase + (uint32_t)(cur.t >> 1), u_pair[0], u_pair[1]);
         bool accepted = false;
         double sn = 0.0, cs = 1.0, lvl = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (!accepted && (h == 0 || ch.t < a.max_tries) && !(REPLAY && (ch.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
-                const double uu = REPLAY ? replay_take(ch) : u_pair[h];
-                const double theta = fma(ch.hi - ch.lo, uu, ch.lo);  // mcmc.py:395
-                ++ch.t;
+            if (!accepted && (h == 0 || cur.t < a.max_tries) && !(REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
+                const double uu = REPLAY ? replay_take() : u_pair[h];
+                const double theta = fma(cur.hi - cur.lo, uu, cur.lo);  // mcmc.py:395
+                ++cur.t;
                 fm::sincos_small(theta, sn, cs);
-                lvl = tp.level(ch.cf, cs, sn);
-                accepted = lvl > ch.thr;                              // mcmc.py:397
-                if (!accepted && shrink) {                            // mcmc.py:400
+                lvl = tp.level(cur.cf, cs, sn);
+                accepted = lvl > cur.thr;                               // mcmc.py:397
+                if (!accepted && shrink) {                              // mcmc.py:400
                     if (theta < 0.0)
-                        ch.lo = theta;
+                        cur.lo = theta;
                     else
-                        ch.hi = theta;
+                        cur.hi = theta;
                 }
             }
         }
-        const bool exhausted = REPLAY && (ch.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
+        const bool exhausted = REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
         if (accepted) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) ch.x[j] = fma(sn, ch.u[j], cs * ch.x[j]);  // mcmc.py:396
-            ch.lvl = lvl;
-            ch.n_try += ch.t;
-            ++ch.steps_done;
-            if (a.samples != nullptr && --ch.until_keep == 0) {
-                ch.until_keep = thin;
+            for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
+            cur.lvl = lvl;
+            cur.n_try += cur.t;
+            ++cur.steps_done;
+            if (a.samples != nullptr && --cur.until_keep == 0) {
+                cur.until_keep = thin;
 #pragma unroll
-                for (int j = 0; j < D; ++j) a.samples[((size_t)ch.row * D + j) * n + ch.id] = ch.x[j];
-                ++ch.row;
+                for (int j = 0; j < D; ++j) a.samples[((size_t)cur.row * D + j) * n + chain_id()] = cur.x[j];
+                ++cur.row;
             }
-            ch.status = (ch.steps_done < n_steps && !exhausted) ? kPending : kDone;
+            cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
         } else if (exhausted) {
-            ch.n_try += ch.t;
-            ch.status = kDone;
+            cur.n_try += cur.t;
+            cur.status = kDone;
         }
     };
 
-    auto swap = [](Chain &p, Chain &q) {
-        Chain tmp = p;
-        p = q;
-        q = tmp;
+    // current chain <-> parked chain
+    auto trade = [&]() {
+        unsigned long long *p = park;
+        auto word = [&](double &v) {
+            lds_trade(v, p);
+            p += kBlock;
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) word(cur.x[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) word(cur.u[j]);
+        cur.cf.each(word);
+        word(cur.lo);
+        word(cur.hi);
+        word(cur.thr);
+        word(cur.lvl);
+        lds_trade(cur.n_try, p);
+        p += kBlock;
+        lds_trade(cur.steps_done, cur.until_keep, p);
+        p += kBlock;
+        lds_trade(cur.row, cur.t, p);
+        p += kBlock;
+        lds_trade(cur.cursor, cur.pad, p);
+        // the status words stay in registers for the wave-level votes
+        const int32_t st = cur.status, er = cur.err;
+        p += kBlock;
+        int32_t pst = st, per = er;
+        lds_trade(pst, per, p);
+        cur.status = pst;
+        cur.err = per;
+        parked_status = st;
+        slot ^= 1;
     };
 
-    Chain cur, oth;
-    const int32_t base = (int32_t)blockIdx.x * kFastChainsPerBlock + (int32_t)threadIdx.x;
-    init(cur, base);
-    init(oth, base + kBlock);
-    if (cur.status == kPending) setup(cur);
-    if (oth.status == kPending) setup(oth);
-    if (cur.status != kReady && oth.status == kReady) swap(cur, oth);
+    auto flush = [&]() {
+        const int32_t c = chain_id();
+        if (c >= n) return;
+#pragma unroll
+        for (int j = 0; j < D; ++j) a.state[(size_t)j * n + c] = cur.x[j];
+        // every accepted step has exactly one non-rejected proposal (counters of a chain that
+        // stopped with an error bit are not specified beyond that bit)
+        if (a.n_reject) a.n_reject[c] += cur.n_try - cur.steps_done;
+        if (a.n_tries) a.n_tries[c] += cur.n_try;
+        if (a.err && cur.err) a.err[c] |= cur.err;
+    };
+
+    // chain of slot 1 is initialised, set up and parked; then the chain of slot 0
+    slot = 1;
+    init();
+    if (cur.status == kPending) setup();
+    {   // plain stores: the slot holds nothing yet
+        unsigned long long *p = park;
+        auto put = [&](double v) {
+            *p = (unsigned long long)__double_as_longlong(v);
+            p += kBlock;
+        };
+        auto put2 = [&](int32_t lo32, int32_t hi32) {
+            *p = (unsigned long long)(uint32_t)lo32 | ((unsigned long long)(uint32_t)hi32 << 32);
+            p += kBlock;
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) put(cur.x[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) put(cur.u[j]);
+        cur.cf.each([&](double &v) { put(v); });
+        put(cur.lo);
+        put(cur.hi);
+        put(cur.thr);
+        put(cur.lvl);
+        *p = (unsigned long long)cur.n_try;
+        p += kBlock;
+        put2(cur.steps_done, cur.until_keep);
+        put2(cur.row, cur.t);
+        put2(cur.cursor, cur.pad);
+        put2(cur.status, cur.err);
+        parked_status = cur.status;
+    }
+    slot = 0;
+    init();
+    if (cur.status == kPending) setup();
+    if (cur.status != kReady && parked_status == kReady) trade();
 
     for (;;) {
         if (cur.status == kReady) {
-            attempt(cur);
-            if (cur.status != kReady && oth.status == kReady) swap(cur, oth);
+            attempt();
+            if (cur.status != kReady && parked_status == kReady) trade();
         }
-        const unsigned long long live = __ballot(cur.status != kDone || oth.status != kDone);
+        const unsigned long long live = __ballot(cur.status != kDone || parked_status != kDone);
         if (live == 0ull) break;
         const unsigned long long waiting = __ballot(cur.status == kPending);  // nothing to try until set up
-        const unsigned long long pend = __ballot(cur.status == kPending || oth.status == kPending);
+        const unsigned long long pend = __ballot(cur.status == kPending || parked_status == kPending);
         const int n_live = __popcll(live);
         if (pend != 0ull && (2 * __popcll(waiting) >= n_live || 8 * __popcll(pend) >= 7 * n_live)) {
-            if (cur.status == kPending && oth.status != kPending) swap(cur, oth);
-            if (oth.status == kPending) setup(oth);
-            if (cur.status != kReady && oth.status == kReady) swap(cur, oth);
+            if (cur.status != kPending && parked_status == kPending) trade();  // bring the waiting chain in
+            if (cur.status == kPending) setup();
         }
     }
-
-    auto flush = [&](const Chain &ch) {
-        if (ch.id < 0) return;
-#pragma unroll
-        for (int j = 0; j < D; ++j) a.state[(size_t)j * n + ch.id] = ch.x[j];
-        // every accepted step has exactly one non-rejected proposal (counters of a chain that
-        // stopped with an error bit are not specified beyond that bit)
-        if (a.n_reject) a.n_reject[ch.id] += ch.n_try - ch.steps_done;
-        if (a.n_tries) a.n_tries[ch.id] += ch.n_try;
-        if (a.err && ch.err) a.err[ch.id] |= ch.err;
-    };
-    flush(cur);
-    flush(oth);
+    flush();
+    trade();
+    flush();
 }
 
 // host side: launch one instantiation
@@ -354,7 +463,7 @@ void set_error(const char *fmt, ...);
 template <int D, class TP, bool REPLAY>
 int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
-    const size_t lds = TP::lds_doubles() * sizeof(double);
+    const size_t lds = fast_lds_doubles<D, TP>() * sizeof(double);
     auto kern = fast_kernel<D, TP, REPLAY>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
