@@ -26,6 +26,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6    # vendor vector-FP64 figure
 
+# algorithmic FP64 flops (FMA = 2) of the restricted-form algorithm, per step and per try: DESIGN.md "Roofline"
+FLOPS_SETUP = {"vmfmix_readme": 240.0, "vmfmix_k10_kappa500": 324.0, "bingham_d10": 1060.0}
+FLOPS_TRY = {"vmfmix_readme": 152.0, "vmfmix_k10_kappa500": 411.0, "bingham_d10": 48.0}
+# HBM bytes per launch from the rocprofv3 PMC passes (profiles/), corrected as MI355X_MICROARCH.md prescribes;
+# filled in from the committed profile of the default workload
+TRAFFIC_BYTES_PER_LAUNCH = {"vmfmix_readme": 2 * 19744.3e3 + 62682.5e3}  # profiles/r01_*_summary.md: 2*FETCH_SIZE + WRITE_SIZE
+
 README_MUS = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
 
 
@@ -50,27 +57,65 @@ def oracle_target(orc, name):
     return None
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload, d, budget_s=12.0):
     """The CPU oracle (C restatement of the reference loop, oracle/gsss_oracle.c) timed on the
-    host cores on a bounded sample of the same workload."""
+    host cores on a bounded sample of the same workload (same target, same sampler, Philox stream)."""
     from oracle import oracle as orc
     tgt = oracle_target(orc, workload)
     if tgt is None:
         return None
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
-    x0 = orc.sample_sphere(0, 4096, d)
+    cores = host_cores()
+    x0 = orc.sample_sphere(0, 1024 * cores, d)
     t0 = time.perf_counter()
-    orc.run(tgt, x0, 20, seed=3521, keep_samples=False, n_threads=cores)
-    rate = 4096 * 20 / (time.perf_counter() - t0)
+    orc.run(tgt, x0, 10, seed=3521, keep_samples=False, n_threads=cores)
+    rate = len(x0) * 10 / (time.perf_counter() - t0)
     n_chains = 4096 * cores
-    n_steps = int(max(20, min(2000, budget_s * rate / n_chains)))
+    n_steps = int(max(50, budget_s * rate / n_chains))
     x0 = orc.sample_sphere(0, n_chains, d)
     t0 = time.perf_counter()
     out = orc.run(tgt, x0, n_steps, seed=3521, keep_samples=False, n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": n_chains * n_steps / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_chains} chains x {n_steps} steps of the same target, OpenMP over chains, {dt:.1f} s",
-            "tries_per_step": float(out["n_tries"].sum() / (n_chains * n_steps))}
+            "sample": f"{n_chains} chains x {n_steps} steps of the same target and sampler, C oracle with OpenMP over "
+                      f"chains on {cores} threads, {dt:.1f} s",
+            "tries_per_step": float(out["n_tries"].sum() / (n_chains * n_steps)),
+            "reference_numpy_note": "the reference itself (pure NumPy, one chain per process) runs this target at "
+                                    "~1.0-1.4e3 steps/s per core (BASELINE.md, measured in the build container)"}
+
+
+def ess_per_sec(gs, pdf, d, seed, steps_per_sec_per_chain_total, n_chains=512, n_draws=4000):
+    """Effective samples per second (secondary metric): mean over a chain subsample of
+    n_eff = n / IAT of the first coordinate (IAT estimated by the initial-positive-sequence
+    rule on the FFT autocorrelation, the estimator family of geosss/utils.py:109-134), scaled to
+    the measured whole-job step rate."""
+    import torch
+    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=1).T
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed)
+    s.advance(200)
+    X = s.sample(n_draws, as_tensor=True)[:, :, 0]               # (chains, draws)
+    X = X - X.mean(dim=1, keepdim=True)
+    n = X.shape[1]
+    f = torch.fft.rfft(X, n=2 * n, dim=1)
+    acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=1)[:, :n]
+    acf = acf / acf[:, :1]
+    pair = acf[:, 0:n - 1:2] + acf[:, 1:n:2]                      # Geyer: sums of adjacent pairs
+    positive = torch.cumprod((pair > 0).to(torch.float64), dim=1)
+    iat = torch.clamp(2.0 * (pair * positive).sum(dim=1) - 1.0, min=1.0)
+    rel = float((1.0 / iat).mean().item())                         # ESS per step
+    return {"ess_per_step": rel, "ess_per_sec": rel * steps_per_sec_per_chain_total,
+            "estimator": f"first coordinate, Geyer initial positive sequence, {n_chains} chains x {n_draws} draws"}
 
 
 def main():
@@ -81,9 +126,10 @@ def main():
     ap.add_argument("--chains", type=int, default=1_000_000, help="chains per GPU")
     ap.add_argument("--inner", type=int, default=100, help="MCMC transitions per launch (= per bench step)")
     ap.add_argument("--workload", default="vmfmix_readme")
-    ap.add_argument("--mode", default="exact")
+    ap.add_argument("--mode", default="auto")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -150,12 +196,15 @@ def main():
     value = total_steps / elapsed
 
     if rank == 0:
-        # algorithmic HBM bytes per chain-step: retained sample 8d/thin + state
-        # load/store 16d/S + counters (3 x 8-byte read-modify-write words + err) / S
-        bytes_per_step = 8.0 * d / S + (16.0 * d + 48.0) / S
+        # algorithmic HBM bytes per chain-step (DESIGN.md "Roofline"): retained sample 8d/thin (thin = S here)
+        # + state load/store 16d/S + per-chain counters (two int64 read-modify-writes = 32 B) / S
+        bytes_per_step = 8.0 * d / S + (16.0 * d + 32.0) / S
         bytes_per_launch = bytes_per_step * n * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
+        mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
+        # algorithmic FP64 flops per chain-step (DESIGN.md "Roofline"): setup + tries x per-try
+        flops_step = FLOPS_SETUP.get(args.workload, 0.0) + (tries / total_steps) * FLOPS_TRY.get(args.workload, 0.0)
         out = {
             "metric": "mcmc_chain_steps_per_sec", "value": value, "unit": "chain-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -163,17 +212,24 @@ def main():
             "config": {"workload": f"{args.workload}: shrinkage slice sampler, {n} chains/GPU x {S} transitions per "
                                    "launch, thin=%d, Philox4x32-10 stream" % S,
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S,
-                       "mode": args.mode,
-                       "kernel": lib.gsss_variant_name(sampler._target_dev.handle, 0, args.variant).decode(),
-                       "sharding": f"{world} x independent chain blocks, final states all-gathered" if world > 1
-                       else "single GPU"},
+                       "mode": sampler.mode,
+                       "kernel": lib.gsss_variant_name(sampler._target_dev.handle, mode_id, args.variant).decode(),
+                       "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"
+                       if world > 1 else "single GPU"},
             "tries_per_step": tries / total_steps, "chains_in_error": bad,
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "state stays in registers across the launch; the path is FP64-VALU/transcendental "
-                                 "bound, see DESIGN.md"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(args.workload),
+                         "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
+                                 "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
+                                 "issue (see roofline_valu and DESIGN.md)"},
+            "roofline_valu": {"bound": "fp64_valu", "achieved": flops_step * n * S / (kern_ms * 1e-3) / 1e12,
+                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": flops_step * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                              "flops_per_chain_step": flops_step},
         }
+        if world == 1 and not args.no_ess:
+            out["ess"] = ess_per_sec(gs, pdf, d, 3521, value)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, d)
         print(json.dumps(out))

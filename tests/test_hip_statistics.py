@@ -1,0 +1,129 @@
+"""Statistical parity at BASELINE.json's full sizes (10^5-10^6 chains): quantities the reference
+pins (tests/golden/stats_*.npz: 8 independent reference chains each) and analytic properties of the
+targets.  Size-independent checks: these hold for any number of chains, the large ensembles only
+shrink the Monte-Carlo error."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from helpers import product_target
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gs():
+    import torch
+    assert torch.cuda.is_available()
+    import geosss_amd
+    return geosss_amd
+
+
+def _run(gs, pdf, x0, n_steps, burn, **kw):
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=20240607, **kw)
+    s.advance(burn)
+    r0, t0 = s.n_reject, int(s.n_tries_per_chain.sum())
+    prev = s.state_rows().clone()
+    s.advance(n_steps)
+    assert np.all(s.errors == 0)
+    n = s.n_chains
+    rej = (s.n_reject - r0) / (n * n_steps)
+    tries = (int(s.n_tries_per_chain.sum()) - t0) / (n * n_steps)
+    return s, rej, tries, prev
+
+
+def test_vmf_mixture_cfg2_one_million_chains(gs):
+    """README target, 10^6 chains: rejections/step as the reference (2 %), tries = rejections + 1,
+    stationary mean and mode masses equal to the analytic values of the mixture."""
+    import torch
+    z, st = golden("traj_vmfmix_readme.npz"), golden("stats_vmfmix_readme.npz")
+    pdf = product_target(z)
+    n = 1_000_000
+    x0 = gs.sample_sphere_device(2, n, seed=9).T
+    s, rej, tries, _ = _run(gs, pdf, x0, 200, 3000)
+    assert s.mode == "fast"
+    ref = float(st["rej_per_step"].mean())
+    assert abs(rej - ref) / ref < 0.02, (rej, ref)
+    assert abs(tries - rej - 1.0) < 1e-12
+    # analytic mixture: component mass ~ w_k e^{c_k} 4 pi sinh(kappa_k)/kappa_k, E[x] = sum pi_k A(kappa_k) mu_k/|mu_k|
+    mu = z["target_mu"]
+    kappa = np.linalg.norm(mu, axis=1)
+    from scipy.special import ive
+    logmass = np.log(z["target_weights"]) - (np.log(ive(0, kappa)) + kappa) + kappa - np.log(kappa)  # up to a constant
+    pi = np.exp(logmass - logmass.max())
+    pi /= pi.sum()
+    modes = mu / kappa[:, None]
+    mean_true = (pi * (1 / np.tanh(kappa) - 1 / kappa)) @ modes
+    X = s.state_rows()
+    mean = X.mean(0).cpu().numpy()
+    assert np.max(np.abs(mean - mean_true)) < 6e-3, (mean, mean_true)
+    occ = torch.bincount(torch.argmax(X @ torch.from_numpy(modes.T).to(X), dim=1), minlength=3).cpu().numpy() / n
+    assert np.max(np.abs(occ - pi)) < 6e-3, (occ, pi)
+    assert np.max(np.abs(occ - st["occupancy"].mean(0))) < 0.05  # the reference's own (noisier) estimate
+    # the state is never renormalised (reference quirk) but must stay on the sphere to rounding
+    assert float((X.norm(dim=1) - 1).abs().max()) < 1e-9
+
+
+def test_vmf_mixture_cfg5_k10_kappa500(gs):
+    z, st = golden("traj_vmfmix_k10_kappa500.npz"), golden("stats_vmfmix_k10_kappa500.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere_device(2, 1_000_000, seed=10).T
+    s, rej, tries, _ = _run(gs, pdf, x0, 100, 500)
+    assert s.mode == "fast"
+    ref = float(st["rej_per_step"].mean())
+    assert abs(rej - ref) / ref < 0.02, (rej, ref)
+
+
+def test_bingham_cfg3_one_million_chains(gs):
+    """Bingham d=10 (scripts/bingham.py target): rejections/step, mean geodesic step (the
+    reference publishes 0.54, scripts/Bingham.ipynb:277) and second moments vs the reference chains."""
+    import torch
+    z, st = golden("traj_bingham_d10_vmax30.npz"), golden("stats_bingham_d10_vmax30.npz")
+    pdf = product_target(z)
+    n = 1_000_000
+    x0 = np.repeat(z["x0"][None], n, axis=0)  # every chain starts at the mode, as the script does
+    s, rej, tries, prev = _run(gs, pdf, x0, 1, 1500)
+    # one extra step measured exactly: geodesic distance between consecutive states
+    X = s.state_rows()
+    geo = torch.arccos(torch.clamp((X * prev).sum(1), -1, 1)).mean().item()
+    assert abs(geo - float(st["geo_step"].mean())) / float(st["geo_step"].mean()) < 0.03, geo
+    assert abs(geo - 0.54) < 0.02
+    s2, rej, tries, _ = _run(gs, pdf, X, 100, 0)
+    ref = float(st["rej_per_step"].mean())
+    assert abs(rej - ref) / ref < 0.02, (rej, ref)
+    second = (X[:, :, None] * X[:, None, :]).mean(0).cpu().numpy()
+    ref2 = st["second"].mean(0)
+    tol = 4 * st["second"].std(0) / np.sqrt(len(st["second"])) + 2e-3
+    assert np.all(np.abs(second - ref2) < tol), np.max(np.abs(second - ref2) / tol)
+    assert abs(np.trace(second) - 1.0) < 1e-9
+
+
+def test_curve_vmf_cfg4(gs):
+    """curve-vMF d=10 kappa=800, 10^5 chains (exact kernels): rejections/step and step length."""
+    import torch
+    z, st = golden("traj_curve_d10_kappa800.npz"), golden("stats_curve_d10_kappa800.npz")
+    pdf = product_target(z)
+    n = 100_000
+    x0 = np.repeat(z["x0"][None], n, axis=0)
+    s, rej, tries, _ = _run(gs, pdf, x0, 30, 300)
+    ref = float(st["rej_per_step"].mean())
+    assert abs(rej - ref) / ref < 0.03, (rej, ref)
+    prev = s.state_rows().clone()
+    s.advance(1)
+    geo = torch.arccos(torch.clamp((s.state_rows() * prev).sum(1), -1, 1)).mean().item()
+    refg = float(st["geo_step"].mean())
+    assert abs(geo - refg) / refg < 0.06, (geo, refg)
+
+
+def test_rejection_sampler_statistics(gs):
+    """geoSSS (reject) on the Bingham target: mean geodesic step 1.58 (scripts/Bingham.ipynb:276)."""
+    import torch
+    z = golden("traj_bingham_d10_vmax30.npz")
+    pdf = product_target(z)
+    n = 200_000
+    s = gs.RejectionSphericalSliceSampler(pdf, np.repeat(z["x0"][None], n, axis=0), seed=3)
+    s.advance(100)
+    prev = s.state_rows().clone()
+    s.advance(1)
+    geo = torch.arccos(torch.clamp((s.state_rows() * prev).sum(1), -1, 1)).mean().item()
+    assert abs(geo - 1.58) < 0.03, geo
