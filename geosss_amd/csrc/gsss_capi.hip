@@ -162,6 +162,7 @@ static int fast_dispatch(const gsss::TargetBlock &tb, const gsss::RunBlock &rb, 
     switch (tb.kind) {
     case GSSS_VMF_MIXTURE: return gsss::launch_fast_vmf(tb, rb, replay, probe, st);
     case GSSS_BINGHAM: return gsss::launch_fast_bingham(tb, rb, replay, probe, st);
+    case GSSS_CURVE_VMF: return gsss::launch_fast_curve(tb, rb, replay, probe, st);
     }
     if (!probe) gsss::set_error("fast mode is not built for target kind %d", tb.kind);
     return GSSS_E_UNSUPPORTED;

@@ -26,8 +26,6 @@
 
 namespace gsss {
 
-constexpr int kChainsPerLane = 2;
-constexpr int kFastChainsPerBlock = kBlock * kChainsPerLane;
 
 enum : int32_t { kReady = 0, kPending = 1, kDone = 2 };
 
@@ -151,6 +149,89 @@ struct FastBingham {
     }
 };
 
+template <int D, int NK>
+struct FastCurve {
+    static constexpr bool kLinear = false;
+    const double *knots;  // LDS [NK][D]
+    const double *seg;    // LDS [NK-1][4]: cos(theta_s), sin(theta_s), 1/(sin(theta_s)+1e-10), unused
+    double kappa;
+    struct Coef {
+        double ax[NK], au[NK];  // a_i . x, a_i . u
+        template <class F>
+        __device__ __forceinline__ void each(F &&f)
+        {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) f(ax[i]);
+#pragma unroll
+            for (int i = 0; i < NK; ++i) f(au[i]);
+        }
+    };
+    static constexpr int kCoefWords = 2 * NK;
+    __host__ __device__ static size_t lds_doubles() { return (size_t)NK * D + 4 * (size_t)(NK - 1); }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        kappa = tb.kappa;
+        for (int i = threadIdx.x; i < NK * D; i += kBlock) lds[i] = tb.blob[i];
+        double *sg = lds + NK * D;
+        for (int i = threadIdx.x; i < NK - 1; i += kBlock) {  // blob: theta, cos, sin, sin + 1e-10
+            sg[4 * i + 0] = tb.blob[(size_t)NK * D + 4 * i + 1];
+            sg[4 * i + 1] = tb.blob[(size_t)NK * D + 4 * i + 2];
+            sg[4 * i + 2] = 1.0 / tb.blob[(size_t)NK * D + 4 * i + 3];
+            sg[4 * i + 3] = 0.0;
+        }
+        knots = lds;
+        seg = sg;
+    }
+    // kappa * (y . nearest point of the curve), spherical_curve.py:10-32 without trigonometry:
+    // with A = (a.y) sin(th), B = b.y - (a.y) cos(th), t = atan2(B, A) clipped to [0, th] has
+    //   t = 0 when B <= 0,  t = th when A < cos(th) hypot(A, B),  else sin t = B/h, cos t = A/h,
+    // and y . near = (sin(th - t) (a.y) + sin(t) (b.y)) / (sin(th) + 1e-10).  The nearest segment is
+    // the first one of minimal acos(clip(y.near)) = the first one of maximal clipped y.near.
+    __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
+    {
+        double best = -INFINITY, best_dot = 0.0;
+        double ay = fma(c, cf.ax[0], s * cf.au[0]);
+#pragma unroll
+        for (int g = 0; g + 1 < NK; ++g) {
+            const double by = fma(c, cf.ax[g + 1], s * cf.au[g + 1]);
+            const double ct = seg[4 * g], st = seg[4 * g + 1], rden = seg[4 * g + 2];
+            const double A = ay * st;
+            const double B = fma(-ay, ct, by);
+            const double h2 = fma(A, A, B * B);
+            const double rh = h2 > 0.0 ? 1.0 / sqrt(h2) : 0.0;
+            const double inner = fma(fma(st, A, -ct * B), ay, B * by) * rh;  // sin(th-t) a.y + sin(t) b.y
+            const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
+            const bool at_b = A * rh < ct;
+            const double num = at_a ? st * ay : (at_b ? st * by : inner);
+            const double xy = num * rden;
+            const double xc = fmin(fmax(xy, -1.0), 1.0);
+            if (xc > best) {
+                best = xc;
+                best_dot = xy;
+            }
+            ay = by;
+        }
+        return kappa * best_dot;
+    }
+    __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D], double /*lvl*/,
+                                           bool /*fresh*/) const
+    {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            double ax = 0.0, au = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double kij = knots[i * D + j];
+                ax = fma(kij, x[j], ax);
+                au = fma(kij, u[j], au);
+            }
+            cf.ax[i] = ax;
+            cf.au[i] = au;
+        }
+        return level(cf, 1.0, 0.0);
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // per-chain state: only what must survive between tries.  RNG counters are rebuilt from
 // (id, steps_done, t) when a draw is needed.  A lane keeps its current chain in registers and
@@ -187,10 +268,21 @@ __device__ __forceinline__ void lds_trade(int32_t &a, int32_t &b, unsigned long 
     b = (int32_t)(uint32_t)(o >> 32);
 }
 
+// a second chain per lane is parked in LDS only while that leaves room for >= 2 workgroups per CU
+template <int D, class TP>
+__host__ __device__ constexpr bool fast_parks()
+{
+    return (size_t)FastChain<D, TP>::kWords * kBlock * sizeof(double) <= 72 * 1024;
+}
+template <int D, class TP>
+__host__ __device__ constexpr int fast_chains_per_block()
+{
+    return fast_parks<D, TP>() ? 2 * kBlock : kBlock;
+}
 template <int D, class TP>
 __host__ __device__ constexpr size_t fast_lds_doubles()
 {
-    return TP::lds_doubles() + (size_t)FastChain<D, TP>::kWords * kBlock;
+    return TP::lds_doubles() + (fast_parks<D, TP>() ? (size_t)FastChain<D, TP>::kWords * kBlock : 0);
 }
 
 template <int D, class TP, bool REPLAY>
@@ -210,7 +302,8 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int32_t thin = (int32_t)a.thin;
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
-    const int32_t base = (int32_t)blockIdx.x * kFastChainsPerBlock + (int32_t)threadIdx.x;
+    constexpr bool kPark = fast_parks<D, TP>();
+    const int32_t base = (int32_t)blockIdx.x * fast_chains_per_block<D, TP>() + (int32_t)threadIdx.x;
 
     Chain cur;
     int32_t slot = 0;               // which of the lane's two chains `cur` is: id = base + slot * kBlock
@@ -402,10 +495,11 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     };
 
     // chain of slot 1 is initialised, set up and parked; then the chain of slot 0
-    slot = 1;
-    init();
-    if (cur.status == kPending) setup();
-    {   // plain stores: the slot holds nothing yet
+    if (kPark) {
+        slot = 1;
+        init();
+        if (cur.status == kPending) setup();
+        // plain stores: the slot holds nothing yet
         unsigned long long *p = park;
         auto put = [&](double v) {
             *p = (unsigned long long)__double_as_longlong(v);
@@ -453,8 +547,10 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         }
     }
     flush();
-    trade();
-    flush();
+    if (kPark) {
+        trade();
+        flush();
+    }
 }
 
 // host side: launch one instantiation
@@ -473,7 +569,8 @@ int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
             return GSSS_E_HIP;
         }
     }
-    const int64_t grid = (rb.n_chains + kFastChainsPerBlock - 1) / kFastChainsPerBlock;
+    constexpr int per_block = fast_chains_per_block<D, TP>();
+    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -493,5 +590,6 @@ int do_fast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t 
 // covers (d, k).  `probe` = only answer whether a kernel exists.
 int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
 int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
+int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
 
 }  // namespace gsss

@@ -1,0 +1,21 @@
+// GSSS_MODE_FAST instantiations for curve-vMF targets (10 knots, the reference's brownian_curve default).
+#include "gsss_fast.h"
+
+namespace gsss {
+
+#define GSSS_FAST_CURVE_DIMS(X) X(3) X(6) X(10) X(12) X(24)
+
+int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
+{
+#define GSSS_CASE(D)                                                \
+    if (tb.d == D && tb.k == 10) {                                  \
+        if (probe) return GSSS_OK;                                  \
+        return do_fast<D, FastCurve<D, 10>>(tb, rb, replay, st);    \
+    }
+    GSSS_FAST_CURVE_DIMS(GSSS_CASE)
+#undef GSSS_CASE
+    if (!probe) set_error("fast mode is not built for a curve-vMF target with d=%d, %d knots", tb.d, tb.k);
+    return GSSS_E_UNSUPPORTED;
+}
+
+}  // namespace gsss

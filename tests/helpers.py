@@ -39,6 +39,7 @@ def pad_replay(draws, offsets):
 # shapes the GSSS_MODE_FAST kernels are built for (geosss_amd/csrc/gsss_fast_*.hip)
 FAST_VMF = {(3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 10), (4, 4), (10, 5)}
 FAST_BINGHAM = {3, 4, 5, 10}
+FAST_CURVE = {(3, 10), (6, 10), (10, 10), (12, 10), (24, 10)}  # (d, knots)
 
 
 def fast_supported(z, prefix="target_"):
@@ -48,6 +49,9 @@ def fast_supported(z, prefix="target_"):
         return (d, k) in FAST_VMF
     if kind == "bingham":
         return z[prefix + "A"].shape[0] in FAST_BINGHAM
+    if kind == "curve_vmf":
+        k, d = z[prefix + "knots"].shape
+        return (d, k) in FAST_CURVE
     return False
 
 

@@ -226,7 +226,7 @@ def test_error_reporting(gs):
         gs.ShrinkageSphericalSliceSampler(pdf, np.zeros(4), 1)
     with pytest.raises(ValueError):
         pdf.log_prob(np.zeros((5, 4)))
-    zc = golden("traj_curve_d24_kappa800.npz")
+    zc = golden("traj_curve_d50_kappa800.npz")
     with pytest.raises(ValueError):  # fast mode is not built for this shape: refused, no silent fallback
         gs.ShrinkageSphericalSliceSampler(product_target(zc), zc["x0"], 1, mode="fast").advance(1)
 
