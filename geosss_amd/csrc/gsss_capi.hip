@@ -397,7 +397,11 @@ int gsss_mode_supported(const gsss_target *t, int32_t mode)
 const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t variant)
 {
     if (!t) return "";
-    if (mode == GSSS_MODE_FAST) return gsss_mode_supported(t, mode) ? "fast-lane-2chain" : "";
+    if (mode == GSSS_MODE_FAST) {
+        if (!gsss_mode_supported(t, mode)) return "";
+        const bool lane = t->tb.kind == GSSS_CURVE_VMF ? t->tb.d <= 24 : t->tb.d <= 10;
+        return lane ? "fast-lane" : "fast-coop";
+    }
     const int vec = select_vec(t->tb.d, variant);
     if (vec < 0) return "";
     int n;

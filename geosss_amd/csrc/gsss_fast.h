@@ -44,14 +44,14 @@ struct FastVmf {
     const double *mu;    // LDS [KC][D]
     const double *logc;  // LDS [KC]
     struct Coef {
-        double ax[KC], bu[KC], m;
+        double ax[KC], au[KC], m;
         template <class F>
         __device__ __forceinline__ void each(F &&f)
         {
 #pragma unroll
             for (int k = 0; k < KC; ++k) f(ax[k]);
 #pragma unroll
-            for (int k = 0; k < KC; ++k) f(bu[k]);
+            for (int k = 0; k < KC; ++k) f(au[k]);
             f(m);
         }
     };
@@ -68,15 +68,15 @@ struct FastVmf {
     {
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
-            double ax = 0.0, bu = 0.0;
+            double ax = 0.0, au = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const double mkj = mu[k * D + j];
                 ax = fma(mkj, x[j], ax);
-                bu = fma(mkj, u[j], bu);
+                au = fma(mkj, u[j], au);
             }
             cf.ax[k] = ax;
-            cf.bu[k] = bu;
+            cf.au[k] = au;
         }
         // the offset m only keeps the exponentials in range; re-centre it when the carried level
         // has drifted far from 1 (or on the first step of a launch)
@@ -95,7 +95,7 @@ struct FastVmf {
     {
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; ++k) sum += fm::exp_fast(fma(c, cf.ax[k], fma(s, cf.bu[k], logc[k])) - cf.m);
+        for (int k = 0; k < KC; ++k) sum += fm::exp_fast(fma(c, cf.ax[k], fma(s, cf.au[k], logc[k])) - cf.m);
         return sum;
     }
 };
@@ -591,5 +591,286 @@ int do_fast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t 
 int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
 int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
 int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
+
+}  // namespace gsss
+
+// ==========================================================================================
+// Cooperative fast kernels: large d.  L lanes share one chain (CoopVec), the O(d) work of a step
+// (normals, projection, dots with the target's parameter vectors, state update) is spread over the
+// lanes, the O(1)-per-try restricted form is evaluated redundantly by every lane of the group (all
+// lanes hold identical bits after the xor-butterfly, so the group never diverges internally).
+// The coefficients a_i.x follow the exact recurrence a_i.x' = c a_i.x + s a_i.u between refreshes.
+// ==========================================================================================
+namespace gsss {
+
+constexpr int kCoefRefresh = 64;  // recompute a_i.x from x every this many steps (bounds rounding drift)
+
+template <class V, int NK>
+struct CoopCurve {
+    using Scalar = FastCurve<1, NK>;  // only its level() and Coef are used
+    static constexpr bool kLinear = false;
+    static constexpr int kVectors = NK;
+    Scalar sc;
+    const double *rows;  // LDS [NK][DPAD]
+    __host__ __device__ static size_t lds_doubles() { return (size_t)NK * V::DPAD + 4 * (size_t)(NK - 1); }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        lds_fill(lds, NK, V::DPAD, tb.blob, tb.d);
+        double *sg = lds + (size_t)NK * V::DPAD;
+        for (int i = threadIdx.x; i < NK - 1; i += kBlock) {
+            sg[4 * i + 0] = tb.blob[(size_t)NK * tb.d + 4 * i + 1];
+            sg[4 * i + 1] = tb.blob[(size_t)NK * tb.d + 4 * i + 2];
+            sg[4 * i + 2] = 1.0 / tb.blob[(size_t)NK * tb.d + 4 * i + 3];
+            sg[4 * i + 3] = 0.0;
+        }
+        rows = lds;
+        sc.knots = lds;
+        sc.seg = sg;
+        sc.kappa = tb.kappa;
+    }
+    __device__ __forceinline__ double level(const typename Scalar::Coef &cf, double c, double s) const
+    {
+        return sc.level(cf, c, s);
+    }
+    // level of x itself, given fresh coefficients
+    __device__ __forceinline__ double level0(typename Scalar::Coef &cf, double /*carried*/, bool /*fresh*/) const
+    {
+        return sc.level(cf, 1.0, 0.0);
+    }
+};
+
+template <class V, int KC>
+struct CoopVmf {
+    using Scalar = FastVmf<1, KC>;
+    static constexpr bool kLinear = true;
+    static constexpr int kVectors = KC;
+    Scalar sc;
+    const double *rows;  // LDS [KC][DPAD]
+    __host__ __device__ static size_t lds_doubles() { return (size_t)KC * V::DPAD + KC; }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        lds_fill(lds, KC, V::DPAD, tb.blob, tb.d);
+        double *lc = lds + (size_t)KC * V::DPAD;
+        for (int i = threadIdx.x; i < KC; i += kBlock) lc[i] = tb.blob[(size_t)KC * tb.d + i];
+        rows = lds;
+        sc.mu = lds;
+        sc.logc = lc;
+    }
+    __device__ __forceinline__ double level(const typename Scalar::Coef &cf, double c, double s) const
+    {
+        return sc.level(cf, c, s);
+    }
+    __device__ __forceinline__ double level0(typename Scalar::Coef &cf, double carried, bool fresh) const
+    {
+        if (fresh || !(carried > 1e-150 && carried < 1e150)) {
+            double m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + sc.logc[k]);
+            cf.m = m;
+            carried = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) carried += fm::exp_fast((cf.ax[k] + sc.logc[k]) - m);
+        }
+        return carried;
+    }
+};
+
+template <class V, class TP, bool REPLAY>
+__global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlock a)
+{
+    using Coef = typename TP::Scalar::Coef;
+    constexpr int NV = TP::kVectors;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    TP tp;
+    tp.stage(lds, tb);
+    __syncthreads();
+
+    const int d = tb.d;
+    const int g = threadIdx.x % V::L;
+    const int64_t n = a.n_chains;
+    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / V::L) + threadIdx.x / V::L;
+    const bool active = c_raw < n;
+    const int64_t c = active ? c_raw : n - 1;
+    const bool shrink = a.sampler == GSSS_SHRINK;
+    const uint32_t try_base = 1u + (uint32_t)((d + 3) >> 2);
+
+    double x[V::N];
+#pragma unroll
+    for (int i = 0; i < V::N; ++i) {
+        const int cc = V::comp(g, i);
+        x[i] = (cc < d) ? a.state[(size_t)cc * n + c] : 0.0;
+    }
+    auto pdot = [&](const double (&v)[V::N], int r) {  // v . (parameter row r)
+        const double *row = tp.rows + (size_t)r * V::DPAD;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) s = fma(row[V::comp(g, i)], v[i], s);
+        return V::reduce(s);
+    };
+
+    PhiloxDraws<V> dr;
+    dr.init(a, c, d);
+    int64_t cursor = 0;  // replay
+    const double *rp = REPLAY ? a.replay + (size_t)c * a.replay_stride : nullptr;
+    int err = 0;
+    auto take = [&]() -> double {
+        if (cursor >= a.replay_stride) {
+            err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            return 0.5;
+        }
+        return rp[cursor++];
+    };
+
+    Coef cf;
+    double lvl = 0.0;
+    int64_t n_try = 0, steps_done = 0;
+    int64_t until_keep = a.thin, row = 0;
+
+    for (int64_t s = 0; s < a.n_steps && !err; ++s) {
+        dr.begin_step(a.step_offset + (uint64_t)s);
+        double u[V::N], u_thr, u_th0;
+        if (REPLAY) {
+            const bool ok = cursor + d <= a.replay_stride;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) {
+                const int cc = V::comp(g, i);
+                u[i] = (cc < d) ? (ok ? rp[cursor + cc] : 0.5) : 0.0;
+            }
+            if (ok)
+                cursor += d;
+            else {
+                cursor = a.replay_stride;
+                err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            }
+            u_thr = take();
+            u_th0 = shrink ? take() : 0.0;
+        } else {
+            dr.normals(u, g);
+            dr.block(0u, u_thr, u_th0);
+        }
+        {   // u = spherical_projection(z, x)   (sphere.py:29-33)
+            const double rnx = 1.0 / (sqrt(vdot<V>(x, x)) + 1e-100);
+            const double cz = vdot<V>(u, x) * rnx;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);
+            const double rnw = 1.0 / (sqrt(vdot<V>(u, u)) + 1e-100);
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) u[i] *= rnw;
+        }
+        const bool refresh = (s % kCoefRefresh) == 0;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            cf.au[r] = pdot(u, r);
+            if (refresh) cf.ax[r] = pdot(x, r);
+        }
+        const double lvl0 = tp.level0(cf, lvl, s == 0);
+        double thr;
+        bool finite;
+        if (TP::kLinear) {
+            thr = lvl0 * u_thr;
+            finite = lvl0 > 0.0 && lvl0 < INFINITY;
+        } else {
+            thr = lvl0 + fm::log_fast(u_thr);
+            finite = lvl0 > -INFINITY && lvl0 < INFINITY;
+        }
+        if (!finite) {
+            err |= GSSS_CHAIN_NONFINITE;
+            break;
+        }
+        double lo, hi;
+        if (shrink) {
+            hi = kTwoPi * u_th0;
+            lo = hi - kTwoPi;
+        } else {
+            lo = 0.0;
+            hi = kTwoPi;
+        }
+        int t = 0;
+        bool accepted = false;
+        double sn = 0.0, cs = 1.0;
+        while (!accepted) {
+            if (t >= a.max_tries) {
+                err |= GSSS_CHAIN_MAX_TRIES;
+                break;
+            }
+            double up[2];
+            if (!REPLAY) dr.block(try_base + (uint32_t)(t >> 1), up[0], up[1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!accepted && (h == 0 || t < a.max_tries) && !(REPLAY && (err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
+                    const double uu = REPLAY ? take() : up[h];
+                    const double theta = fma(hi - lo, uu, lo);
+                    ++t;
+                    fm::sincos_small(theta, sn, cs);
+                    lvl = tp.level(cf, cs, sn);
+                    accepted = lvl > thr;
+                    if (!accepted && shrink) {
+                        if (theta < 0.0)
+                            lo = theta;
+                        else
+                            hi = theta;
+                    }
+                }
+            }
+            if (REPLAY && (err & GSSS_CHAIN_REPLAY_EXHAUSTED)) break;
+        }
+        n_try += t;
+        if (accepted) {
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
+#pragma unroll
+            for (int r = 0; r < NV; ++r) cf.ax[r] = fma(cs, cf.ax[r], sn * cf.au[r]);
+            ++steps_done;
+            if (a.samples != nullptr && --until_keep == 0) {
+                until_keep = a.thin;
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < V::N; ++i) {
+                        const int cc = V::comp(g, i);
+                        if (cc < d) a.samples[((size_t)row * d + cc) * n + c] = x[i];
+                    }
+                }
+                ++row;
+            }
+        }
+    }
+
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) {
+            const int cc = V::comp(g, i);
+            if (cc < d) a.state[(size_t)cc * n + c] = x[i];
+        }
+        if (g == 0) {
+            if (a.n_reject) a.n_reject[c] += n_try - steps_done;
+            if (a.n_tries) a.n_tries[c] += n_try;
+            if (a.err && err) a.err[c] |= err;
+        }
+    }
+}
+
+template <class V, class TP>
+int do_coopfast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
+{
+    const size_t lds = TP::lds_doubles() * sizeof(double);
+    auto kern = replay ? coopfast_kernel<V, TP, true> : coopfast_kernel<V, TP, false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GSSS_E_HIP;
+        }
+    }
+    const int64_t per_block = kBlock / V::L;
+    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("cooperative fast kernel launch failed: %s", hipGetErrorString(e));
+        return GSSS_E_HIP;
+    }
+    return GSSS_OK;
+}
 
 }  // namespace gsss

@@ -14,6 +14,13 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bo
     }
     GSSS_FAST_CURVE_DIMS(GSSS_CASE)
 #undef GSSS_CASE
+    // larger d: lanes cooperate on one chain
+    if (tb.k == 10 && tb.d > 24 && tb.d <= 512) {
+        if (probe) return GSSS_OK;
+        if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopCurve<CoopVec<16, 4>, 10>>(tb, rb, replay, st);
+        if (tb.d <= 256) return do_coopfast<CoopVec<64, 4>, CoopCurve<CoopVec<64, 4>, 10>>(tb, rb, replay, st);
+        return do_coopfast<CoopVec<64, 8>, CoopCurve<CoopVec<64, 8>, 10>>(tb, rb, replay, st);
+    }
     if (!probe) set_error("fast mode is not built for a curve-vMF target with d=%d, %d knots", tb.d, tb.k);
     return GSSS_E_UNSUPPORTED;
 }

@@ -15,6 +15,16 @@ int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool
     }
     GSSS_FAST_VMF_SHAPES(GSSS_CASE)
 #undef GSSS_CASE
+    // larger d: lanes cooperate on one chain (K = 3, 5 or 10 components)
+#define GSSS_COOP(K)                                                                                          \
+    if (tb.k == K && tb.d > 10 && tb.d <= 256) {                                                              \
+        if (probe) return GSSS_OK;                                                                            \
+        if (tb.d <= 16) return do_coopfast<CoopVec<4, 4>, CoopVmf<CoopVec<4, 4>, K>>(tb, rb, replay, st);     \
+        if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopVmf<CoopVec<16, 4>, K>>(tb, rb, replay, st);   \
+        return do_coopfast<CoopVec<64, 4>, CoopVmf<CoopVec<64, 4>, K>>(tb, rb, replay, st);                   \
+    }
+    GSSS_COOP(3) GSSS_COOP(5) GSSS_COOP(10)
+#undef GSSS_COOP
     if (!probe) set_error("fast mode is not built for a vMF mixture with d=%d, K=%d", tb.d, tb.k);
     return GSSS_E_UNSUPPORTED;
 }

@@ -46,12 +46,12 @@ def fast_supported(z, prefix="target_"):
     kind = str(z[prefix + "kind"])
     if kind == "vmf_mixture":
         k, d = z[prefix + "mu"].shape
-        return (d, k) in FAST_VMF
+        return (d, k) in FAST_VMF or (k in (3, 5, 10) and 10 < d <= 256)  # cooperative fast kernels
     if kind == "bingham":
         return z[prefix + "A"].shape[0] in FAST_BINGHAM
     if kind == "curve_vmf":
         k, d = z[prefix + "knots"].shape
-        return (d, k) in FAST_CURVE
+        return (d, k) in FAST_CURVE or (k == 10 and 24 < d <= 512)  # cooperative fast kernels
     return False
 
 

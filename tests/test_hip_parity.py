@@ -226,7 +226,7 @@ def test_error_reporting(gs):
         gs.ShrinkageSphericalSliceSampler(pdf, np.zeros(4), 1)
     with pytest.raises(ValueError):
         pdf.log_prob(np.zeros((5, 4)))
-    zc = golden("traj_curve_d50_kappa800.npz")
+    zc = golden("traj_bingham_d50_vmax300.npz")
     with pytest.raises(ValueError):  # fast mode is not built for this shape: refused, no silent fallback
         gs.ShrinkageSphericalSliceSampler(product_target(zc), zc["x0"], 1, mode="fast").advance(1)
 
@@ -247,3 +247,37 @@ def test_layout_round_trip(gs):
     gs._lib.check(lib.gsss_samples_to_chains(s.data_ptr(), o.data_ptr(), 130, 7, 3, 0, None))
     torch.cuda.synchronize()
     assert torch.equal(o, s.permute(2, 0, 1).contiguous())
+
+
+SYNTH = [("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
+         ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7)]
+
+
+@pytest.mark.parametrize("kind,d,k", SYNTH)
+def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
+    """Shapes without a reference fixture (every kernel family and layout boundary): device chains
+    (default mode) equal the oracle's on the same Philox stream; log_prob agrees as well."""
+    rng = np.random.default_rng(1000 * d + k)
+    if kind == "vmf":
+        mu = 40.0 * oracle.sample_sphere(5, k, d)
+        w = rng.uniform(0.5, 2.0, k)
+        pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mu], w)
+        tgt = oracle.Target.vmf_mixture(mu, w)
+    elif kind == "bingham":
+        pdf = gs.random_bingham(d=d, vmax=25.0, vmin=-2.0, eigensystem=False, seed=d)
+        tgt = oracle.Target.bingham(pdf.A)
+    else:
+        knots = gs.brownian_curve(k, d, 0.5, seed=d)
+        pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 300.0)
+        tgt = oracle.Target.curve_vmf(knots, 300.0)
+    n_chains, n_steps = (70, 12) if d > 64 else (333, 25)
+    x0 = oracle.sample_sphere(3, n_chains, d)
+    want = oracle.run(tgt, x0, n_steps, seed=77, n_threads=8)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77)
+    kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
+    assert np.all(s.errors == 0)
+    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    assert np.max(np.abs(kept - want["samples"])) < TOL
+    lp = pdf.log_prob(kept[:, -1])
+    ref = tgt.log_prob(kept[:, -1])
+    assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
