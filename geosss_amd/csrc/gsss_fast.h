@@ -628,6 +628,54 @@ struct CoopCurve {
         sc.seg = sg;
         sc.kappa = tb.kappa;
     }
+    // Lane g of a group evaluates segment g (lanes >= NK-1 sit out); an xor-butterfly then picks the
+    // first segment of maximal clipped y.near -- the same choice as the sequential scan.
+    static constexpr bool kDistributed = V::L >= 16;
+    struct Mine {
+        double ax0, au0, ax1, au1, ct, st, rden;
+    };
+    __device__ __forceinline__ Mine mine(const typename Scalar::Coef &cf, int g) const
+    {
+        Mine m{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i + 1 < NK; ++i)
+            if (g == i) {
+                m.ax0 = cf.ax[i];
+                m.au0 = cf.au[i];
+                m.ax1 = cf.ax[i + 1];
+                m.au1 = cf.au[i + 1];
+            }
+        const int gs = g < NK - 1 ? g : 0;
+        m.ct = sc.seg[4 * gs];
+        m.st = sc.seg[4 * gs + 1];
+        m.rden = sc.seg[4 * gs + 2];
+        return m;
+    }
+    __device__ __forceinline__ double level_distributed(const Mine &m, int g, double c, double s) const
+    {
+        const double ay = fma(c, m.ax0, s * m.au0), by = fma(c, m.ax1, s * m.au1);
+        const double A = ay * m.st;
+        const double B = fma(-ay, m.ct, by);
+        const double h2 = fma(A, A, B * B);
+        const double rh = h2 > 0.0 ? 1.0 / sqrt(h2) : 0.0;
+        const double inner = fma(fma(m.st, A, -m.ct * B), ay, B * by) * rh;
+        const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
+        const bool at_b = A * rh < m.ct;
+        const double num = at_a ? m.st * ay : (at_b ? m.st * by : inner);
+        double xy = num * m.rden;
+        double xc = g < NK - 1 ? fmin(fmax(xy, -1.0), 1.0) : -INFINITY;
+        int idx = g;
+#pragma unroll
+        for (int w = 1; w < V::L; w <<= 1) {
+            const double oxc = __shfl_xor(xc, w, 64), oxy = __shfl_xor(xy, w, 64);
+            const int oidx = __shfl_xor(idx, w, 64);
+            const bool take = oxc > xc || (oxc == xc && oidx < idx);
+            xc = take ? oxc : xc;
+            xy = take ? oxy : xy;
+            idx = take ? oidx : idx;
+        }
+        return sc.kappa * xy;
+    }
     __device__ __forceinline__ double level(const typename Scalar::Coef &cf, double c, double s) const
     {
         return sc.level(cf, c, s);
@@ -644,6 +692,10 @@ struct CoopVmf {
     using Scalar = FastVmf<1, KC>;
     static constexpr bool kLinear = true;
     static constexpr int kVectors = KC;
+    static constexpr bool kDistributed = false;
+    struct Mine {};
+    __device__ __forceinline__ Mine mine(const typename Scalar::Coef &, int) const { return Mine{}; }
+    __device__ __forceinline__ double level_distributed(const Mine &, int, double, double) const { return 0.0; }
     Scalar sc;
     const double *rows;  // LDS [KC][DPAD]
     __host__ __device__ static size_t lds_doubles() { return (size_t)KC * V::DPAD + KC; }
@@ -763,7 +815,8 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
             cf.au[r] = pdot(u, r);
             if (refresh) cf.ax[r] = pdot(x, r);
         }
-        const double lvl0 = tp.level0(cf, lvl, s == 0);
+        const auto my = tp.mine(cf, g);
+        const double lvl0 = TP::kDistributed ? tp.level_distributed(my, g, 1.0, 0.0) : tp.level0(cf, lvl, s == 0);
         double thr;
         bool finite;
         if (TP::kLinear) {
@@ -802,7 +855,7 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
                     const double theta = fma(hi - lo, uu, lo);
                     ++t;
                     fm::sincos_small(theta, sn, cs);
-                    lvl = tp.level(cf, cs, sn);
+                    lvl = TP::kDistributed ? tp.level_distributed(my, g, cs, sn) : tp.level(cf, cs, sn);
                     accepted = lvl > thr;
                     if (!accepted && shrink) {
                         if (theta < 0.0)
