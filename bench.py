@@ -51,10 +51,31 @@ def make_target(gs, name):
     raise ValueError(name)
 
 
-def oracle_target(orc, name):
-    if name == "vmfmix_readme":
-        return orc.Target.vmf_mixture(README_MUS)
-    return None
+def oracle_target(orc, gs, name):
+    """The same target for the CPU oracle, from the product object's plain arrays."""
+    pdf, _ = make_target(gs, name)
+    if isinstance(pdf, gs.MixtureModel):
+        return orc.Target.vmf_mixture([p.mu for p in pdf.pdfs], pdf.weights)
+    if isinstance(pdf, gs.Bingham):
+        return orc.Target.bingham(pdf.A)
+    return orc.Target.curve_vmf(pdf.curve.knots, pdf.kappa)
+
+
+REFERENCE_NAMES = {"vmfmix_readme": "vmfmix_readme", "vmfmix_k10_kappa500": "vmfmix_k10_kappa500",
+                   "bingham_d10": "bingham_d10_vmax30", "curve_d10": "curve_d10_kappa800",
+                   "curve_d200": "curve_d200_kappa800"}
+
+
+def reference_timing(workload):
+    """What the reference itself ran at in the build container (tests/golden/cpu_reference_timing.json,
+    written by tests/golden/make_golden.py timing); it cannot run on the GPU box."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "tests", "golden", "cpu_reference_timing.json")))
+        r = t["targets"][REFERENCE_NAMES[workload]]
+        return {"steps_per_s_1_core": r["steps_per_s_1_process"], "steps_per_s_all_cores": r["steps_per_s_aggregate_all_cores"],
+                "cores": t["host"]["cores"], "cpu": t["host"]["cpu"], "where": "build container, geosss itself"}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def host_cores():
@@ -69,13 +90,11 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(workload, d, budget_s=12.0):
+def cpu_baseline(gs, workload, d, budget_s=12.0):
     """The CPU oracle (C restatement of the reference loop, oracle/gsss_oracle.c) timed on the
     host cores on a bounded sample of the same workload (same target, same sampler, Philox stream)."""
     from oracle import oracle as orc
-    tgt = oracle_target(orc, workload)
-    if tgt is None:
-        return None
+    tgt = oracle_target(orc, gs, workload)
     cores = host_cores()
     x0 = orc.sample_sphere(0, 1024 * cores, d)
     t0 = time.perf_counter()
@@ -91,8 +110,20 @@ def cpu_baseline(workload, d, budget_s=12.0):
             "sample": f"{n_chains} chains x {n_steps} steps of the same target and sampler, C oracle with OpenMP over "
                       f"chains on {cores} threads, {dt:.1f} s",
             "tries_per_step": float(out["n_tries"].sum() / (n_chains * n_steps)),
-            "reference_numpy_note": "the reference itself (pure NumPy, one chain per process) runs this target at "
-                                    "~1.0-1.4e3 steps/s per core (BASELINE.md, measured in the build container)"}
+            "reference": reference_timing(workload), "numpy_port": numpy_port_baseline(workload, cores)}
+
+
+def numpy_port_baseline(workload, cores, n_steps=400):
+    """oracle/numpy_port.py -- a per-chain NumPy loop structured like the reference (one chain per
+    process) -- timed on this box: 1 process and one process per available core."""
+    if workload != "vmfmix_readme":
+        return None
+    from oracle import numpy_port
+    x0 = np.array([-0.86, 0.19, -0.47])
+    one = numpy_port.time_chains(README_MUS, x0, n_steps, 1)
+    allc = numpy_port.time_chains(README_MUS, x0, n_steps, cores)
+    return {"steps_per_s_1_core": one, "steps_per_s_all_cores": allc, "cores": cores,
+            "sample": f"{n_steps} steps per chain, one chain per process"}
 
 
 def ess_per_sec(gs, pdf, d, seed, steps_per_sec_per_chain_total, n_chains=512, n_draws=4000):
@@ -126,6 +157,7 @@ def main():
     ap.add_argument("--chains", type=int, default=1_000_000, help="chains per GPU")
     ap.add_argument("--inner", type=int, default=100, help="MCMC transitions per launch (= per bench step)")
     ap.add_argument("--workload", default="vmfmix_readme")
+    ap.add_argument("--thin", type=int, default=0, help="keep every thin-th state (default: one per launch)")
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +189,8 @@ def main():
     sampler = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=3521, chain_offset=chain_offset, mode=args.mode,
                                                 variant=args.variant)
     S = args.inner
-    kept = torch.empty((1, d, n), dtype=torch.float64, device="cuda")
+    thin = args.thin or S
+    kept = torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda")
 
     def barrier():
         torch.cuda.synchronize()
@@ -166,14 +199,14 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sampler.advance(S, thin=S, out=kept)
+        sampler.advance(S, thin=thin, out=kept)
     tries0 = int(sampler._n_tries.sum().item())
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
-        sampler.advance(S, thin=S, out=kept)
+        sampler.advance(S, thin=thin, out=kept)
         b.record()
     final = gather_states(sampler.state_device) if world > 1 else sampler.state_device
     barrier()
@@ -198,7 +231,7 @@ def main():
     if rank == 0:
         # algorithmic HBM bytes per chain-step (DESIGN.md "Roofline"): retained sample 8d/thin (thin = S here)
         # + state load/store 16d/S + per-chain counters (two int64 read-modify-writes = 32 B) / S
-        bytes_per_step = 8.0 * d / S + (16.0 * d + 32.0) / S
+        bytes_per_step = 8.0 * d / thin + (16.0 * d + 32.0) / S
         bytes_per_launch = bytes_per_step * n * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
@@ -210,7 +243,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: shrinkage slice sampler, {n} chains/GPU x {S} transitions per "
-                                   "launch, thin=%d, Philox4x32-10 stream" % S,
+                                   "launch, thin=%d, Philox4x32-10 stream" % thin,
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S,
                        "mode": sampler.mode,
                        "kernel": lib.gsss_variant_name(sampler._target_dev.handle, mode_id, args.variant).decode(),
@@ -219,7 +252,9 @@ def main():
             "tries_per_step": tries / total_steps, "chains_in_error": bad,
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(args.workload),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(args.workload)
+                         if (thin == S == 100 and n == 1_000_000 and sampler.mode == "fast") else None,
                          "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                  "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
                                  "issue (see roofline_valu and DESIGN.md)"},
@@ -231,7 +266,7 @@ def main():
         if world == 1 and not args.no_ess:
             out["ess"] = ess_per_sec(gs, pdf, d, 3521, value)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, d)
+            out["cpu_baseline"] = cpu_baseline(gs, args.workload, d)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

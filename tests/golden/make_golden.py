@@ -305,8 +305,47 @@ def make_stats():
         save(f"stats_{name}.npz", **arrays)
 
 
+def _time_chain(args):
+    name, n_steps, seed = args
+    pdf, x0, _, _ = cases()[name]
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.array(x0), seed)
+    t0 = time.perf_counter()
+    s.sample(n_steps + 1)
+    return n_steps / (time.perf_counter() - t0), s.n_reject / n_steps
+
+
+def make_timing():
+    """The reference itself timed in THIS container: 1 process and one process per core."""
+    import json
+    import platform
+    from concurrent.futures import ProcessPoolExecutor
+
+    ncpu = os.cpu_count()
+    cpu = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][:1]
+    out = {"host": {"cpu": cpu[0] if cpu else platform.processor(), "cores": ncpu, "python": platform.python_version(),
+                    "numpy": np.__version__}, "sampler": "geosss.ShrinkageSphericalSliceSampler", "targets": {}}
+    import scipy
+    out["host"]["scipy"] = scipy.__version__
+    for name, n in (("vmfmix_readme", 6000), ("vmfmix_k10_kappa500", 3000), ("bingham_d10_vmax30", 40000),
+                    ("curve_d10_kappa800", 1500), ("curve_d200_kappa800", 1200)):
+        one, rej = _time_chain((name, n, 1))
+        t0 = time.perf_counter()
+        with ProcessPoolExecutor(ncpu) as ex:
+            res = list(ex.map(_time_chain, [(name, n, 10 + i) for i in range(ncpu)]))
+        wall = time.perf_counter() - t0
+        out["targets"][name] = {"steps_per_s_1_process": one, "steps_per_s_per_process_all_cores": float(np.mean([r[0] for r in res])),
+                                "steps_per_s_aggregate_all_cores": float(np.sum([r[0] for r in res])),
+                                "steps_per_s_aggregate_incl_spawn": ncpu * n / wall, "rejections_per_step": rej,
+                                "n_steps": n}
+        print(name, out["targets"][name])
+    with open(os.path.join(OUT, "cpu_reference_timing.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats"]
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing"]
+    if "timing" in what:
+        make_timing()
     if "traj" in what:
         make_trajectories()
     if "logprob" in what:

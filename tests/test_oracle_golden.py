@@ -164,3 +164,13 @@ def test_oracle_statistics_match_reference(oracle):
             modes = mu / np.linalg.norm(mu, axis=1, keepdims=True)
             occ = np.bincount(np.argmax(X @ modes.T, axis=1), minlength=len(mu)) / len(X)
             assert np.max(np.abs(occ - s["occupancy"].mean(0))) < 0.05, (occ, s["occupancy"].mean(0))
+
+
+def test_numpy_port_reproduces_reference_chain():
+    """oracle/numpy_port.py (the reference-like CPU baseline bench.py times) seeded like the
+    reference's README run reproduces the golden chain exactly (same numpy stream, same arithmetic)."""
+    from oracle import numpy_port
+    t = golden("traj_vmfmix_readme.npz")
+    out, rej = numpy_port.run_chain(numpy_port.VmfMixture(t["target_mu"], t["target_weights"]), t["x0"], 300, 3521)
+    assert np.max(np.abs(out - t["states"][1:301])) < 1e-12
+    assert rej == int((t["tries"][:300] - 1).sum())
