@@ -242,12 +242,15 @@ struct FastChain {
     double x[D], u[D];
     typename TP::Coef cf;
     double lo, hi, thr, lvl;
-    int64_t n_try;
-    int32_t steps_done, until_keep;
-    int32_t row, t;      // t = proposals made in the current step
+    uint32_t n_try;      // proposals made in this launch (saturating)
+    int32_t steps_done, row;
+    int32_t t;           // proposals made in the current step (< 2^26)
     int32_t status, err;
-    int32_t cursor, pad; // replay: draws consumed
-    static constexpr int kWords = 2 * D + TP::kCoefWords + 4 + 1 + 3 + 1;
+    int32_t cursor;      // replay: draws consumed
+    // 64-bit words a parked chain occupies in LDS: the doubles, (steps_done,row), (n_try, t|status|err)
+    // [+ (cursor,0) for replay].  19 words for d = 3, K = 3 -> 4 workgroups per CU.
+    static constexpr int kWordsNoReplay = 2 * D + TP::kCoefWords + 4 + 2;
+    static constexpr int kWords = kWordsNoReplay + 1;
 };
 
 __device__ __forceinline__ void lds_trade(double &v, unsigned long long *slot)
@@ -279,10 +282,12 @@ __host__ __device__ constexpr int fast_chains_per_block()
 {
     return fast_parks<D, TP>() ? 2 * kBlock : kBlock;
 }
-template <int D, class TP>
+template <int D, class TP, bool REPLAY>
 __host__ __device__ constexpr size_t fast_lds_doubles()
 {
-    return TP::lds_doubles() + (fast_parks<D, TP>() ? (size_t)FastChain<D, TP>::kWords * kBlock : 0);
+    return TP::lds_doubles() +
+           (fast_parks<D, TP>() ? (size_t)(REPLAY ? FastChain<D, TP>::kWords : FastChain<D, TP>::kWordsNoReplay) * kBlock
+                                : 0);
 }
 
 template <int D, class TP, bool REPLAY>
@@ -301,6 +306,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     const int32_t n_steps = (int32_t)a.n_steps;
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int32_t thin = (int32_t)a.thin;
+    const int32_t max_tries = a.max_tries < (1 << 26) ? a.max_tries : (1 << 26) - 1;  // t shares a word with the flags
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
     constexpr bool kPark = fast_parks<D, TP>();
     const int32_t base = (int32_t)blockIdx.x * fast_chains_per_block<D, TP>() + (int32_t)threadIdx.x;
@@ -324,19 +330,21 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         return a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor++];
     };
 
+    auto count_tries = [&]() {
+        const uint32_t sum = cur.n_try + (uint32_t)cur.t;
+        cur.n_try = sum < cur.n_try ? 0xFFFFFFFFu : sum;
+    };
     auto init = [&]() {
         const int32_t c = chain_id();
         const bool valid = c < n;
         const int32_t cc = valid ? c : 0;
 #pragma unroll
         for (int j = 0; j < D; ++j) cur.x[j] = a.state[(size_t)j * n + cc];
-        cur.n_try = 0;
+        cur.n_try = 0u;
         cur.steps_done = 0;
-        cur.until_keep = thin;
         cur.row = 0;
         cur.err = 0;
         cur.cursor = 0;
-        cur.pad = 0;
         cur.lvl = 0.0;
         cur.t = 0;
         cur.status = (valid && n_steps > 0) ? kPending : kDone;
@@ -401,8 +409,8 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
 
     // up to two proposals (one Philox block feeds both: the stream hands tries out in pairs)
     auto attempt = [&]() {
-        if (cur.t >= a.max_tries) {
-            cur.n_try += cur.t;
+        if (cur.t >= max_tries) {
+            count_tries();
             cur.err |= GSSS_CHAIN_MAX_TRIES;
             cur.status = kDone;
             return;
@@ -413,7 +421,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         double sn = 0.0, cs = 1.0, lvl = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (!accepted && (h == 0 || cur.t < a.max_tries) && !(REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
+            if (!accepted && (h == 0 || cur.t < max_tries) && !(REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
                 const double uu = REPLAY ? replay_take() : u_pair[h];
                 const double theta = fma(cur.hi - cur.lo, uu, cur.lo);  // mcmc.py:395
                 ++cur.t;
@@ -433,17 +441,16 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
 #pragma unroll
             for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
             cur.lvl = lvl;
-            cur.n_try += cur.t;
+            count_tries();
             ++cur.steps_done;
-            if (a.samples != nullptr && --cur.until_keep == 0) {
-                cur.until_keep = thin;
+            if (a.samples != nullptr && cur.steps_done == (cur.row + 1) * thin) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) a.samples[((size_t)cur.row * D + j) * n + chain_id()] = cur.x[j];
                 ++cur.row;
             }
             cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
         } else if (exhausted) {
-            cur.n_try += cur.t;
+            count_tries();
             cur.status = kDone;
         }
     };
@@ -464,20 +471,21 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         word(cur.hi);
         word(cur.thr);
         word(cur.lvl);
-        lds_trade(cur.n_try, p);
+        lds_trade(cur.steps_done, cur.row, p);
         p += kBlock;
-        lds_trade(cur.steps_done, cur.until_keep, p);
-        p += kBlock;
-        lds_trade(cur.row, cur.t, p);
-        p += kBlock;
-        lds_trade(cur.cursor, cur.pad, p);
-        // the status words stay in registers for the wave-level votes
-        const int32_t st = cur.status, er = cur.err;
-        p += kBlock;
-        int32_t pst = st, per = er;
-        lds_trade(pst, per, p);
-        cur.status = pst;
-        cur.err = per;
+        if (REPLAY) {
+            int32_t zero = 0;
+            lds_trade(cur.cursor, zero, p);
+            p += kBlock;
+        }
+        // (n_try, t | status << 26 | err << 28); the status also stays in a register for the wave-level votes
+        const int32_t st = cur.status;
+        int32_t nt = (int32_t)cur.n_try, packed = cur.t | (cur.status << 26) | (cur.err << 28);
+        lds_trade(nt, packed, p);
+        cur.n_try = (uint32_t)nt;
+        cur.t = packed & 0x3FFFFFF;
+        cur.status = (packed >> 26) & 3;
+        cur.err = (packed >> 28) & 7;
         parked_status = st;
         slot ^= 1;
     };
@@ -489,8 +497,8 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         for (int j = 0; j < D; ++j) a.state[(size_t)j * n + c] = cur.x[j];
         // every accepted step has exactly one non-rejected proposal (counters of a chain that
         // stopped with an error bit are not specified beyond that bit)
-        if (a.n_reject) a.n_reject[c] += cur.n_try - cur.steps_done;
-        if (a.n_tries) a.n_tries[c] += cur.n_try;
+        if (a.n_reject) a.n_reject[c] += (int64_t)cur.n_try - cur.steps_done;
+        if (a.n_tries) a.n_tries[c] += (int64_t)cur.n_try;
         if (a.err && cur.err) a.err[c] |= cur.err;
     };
 
@@ -518,12 +526,9 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         put(cur.hi);
         put(cur.thr);
         put(cur.lvl);
-        *p = (unsigned long long)cur.n_try;
-        p += kBlock;
-        put2(cur.steps_done, cur.until_keep);
-        put2(cur.row, cur.t);
-        put2(cur.cursor, cur.pad);
-        put2(cur.status, cur.err);
+        put2(cur.steps_done, cur.row);
+        if (REPLAY) put2(cur.cursor, 0);
+        put2((int32_t)cur.n_try, cur.t | (cur.status << 26) | (cur.err << 28));
         parked_status = cur.status;
     }
     slot = 0;
@@ -559,7 +564,7 @@ void set_error(const char *fmt, ...);
 template <int D, class TP, bool REPLAY>
 int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
-    const size_t lds = fast_lds_doubles<D, TP>() * sizeof(double);
+    const size_t lds = fast_lds_doubles<D, TP, REPLAY>() * sizeof(double);
     auto kern = fast_kernel<D, TP, REPLAY>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
