@@ -95,7 +95,7 @@ struct FastVmf {
     {
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; ++k) sum += fm::exp_fast(fma(c, cf.ax[k], fma(s, cf.au[k], logc[k])) - cf.m);
+        for (int k = 0; k < KC; ++k) sum += fm::exp_bounded(fma(c, cf.ax[k], fma(s, cf.au[k], logc[k])) - cf.m);
         return sum;
     }
 };

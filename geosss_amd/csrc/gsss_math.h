@@ -73,6 +73,31 @@ GSSS_HD void sincos_2pi(double u, double &so, double &co)
     quadrant_select((int)k & 3, sin_kernel(r), cos_kernel(r), so, co);
 }
 
+// exp(x) for |x| < 2^20 without the range clamp and NaN handling of exp_fast: the arguments of the
+// mixture's accept test are bounded by construction (differences of log-densities of points on the
+// sphere); a non-finite state is caught when a step is set up.  Same polynomial, same rounding.
+GSSS_HD double exp_bounded(double x)
+{
+    const double n = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878680989792e-09);
+    p = fma(p, r, 2.50521083854417187751e-08);
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // exp(x) for any finite x (and -inf): n = round(x / ln 2), degree-13 Taylor on |r| <= ln2/2
 // (truncation 4e-18), scaled by 2^n with ldexp (gradual underflow, overflow to +inf)
 GSSS_HD double exp_fast(double x)

@@ -4,5 +4,6 @@ extern "C" {
 void t_sincos_small(const double *x, long n, double *s, double *c) { for (long i = 0; i < n; ++i) gsss::fm::sincos_small(x[i], s[i], c[i]); }
 void t_sincos_2pi(const double *x, long n, double *s, double *c) { for (long i = 0; i < n; ++i) gsss::fm::sincos_2pi(x[i], s[i], c[i]); }
 void t_exp(const double *x, long n, double *y) { for (long i = 0; i < n; ++i) y[i] = gsss::fm::exp_fast(x[i]); }
+void t_exp_bounded(const double *x, long n, double *y) { for (long i = 0; i < n; ++i) y[i] = gsss::fm::exp_bounded(x[i]); }
 void t_log(const double *x, long n, double *y) { for (long i = 0; i < n; ++i) y[i] = gsss::fm::log_fast(x[i]); }
 }

@@ -70,6 +70,13 @@ def test_exp(lib):
     assert np.max(ulps(y[normal], want[normal])) <= 1.5
     tiny = ~normal  # near / below the normal range: 1 ulp of a subnormal is coarse, allow it
     assert np.all(np.abs(y[tiny] - want[tiny]) <= np.maximum(4e-16 * want[tiny], 1e-323))
+    yb = np.empty_like(x)
+    lib.t_exp_bounded(_p(x), C.c_long(len(x)), _p(yb))
+    assert np.array_equal(yb, y)  # same polynomial, same rounding on the common domain
+    big = np.array([-5000.0, 5000.0, -1e5, 1e5])
+    yb = np.empty_like(big)
+    lib.t_exp_bounded(_p(big), C.c_long(len(big)), _p(yb))
+    assert yb[0] == 0.0 and yb[1] == np.inf and yb[2] == 0.0 and yb[3] == np.inf
     e = np.array([-np.inf, np.inf, -1e4, 1e4, np.nan])
     y = np.empty_like(e)
     lib.t_exp(_p(e), C.c_long(len(e)), _p(y))
