@@ -29,6 +29,10 @@ namespace gsss {
 
 enum : int32_t { kReady = 0, kPending = 1, kDone = 2 };
 
+// 1 / (sqrt(s) + 1e-100) of sphere.py:14 as one reciprocal square root; the 1e-100 only matters for
+// the zero vector, whose projection the reference maps to zero
+__device__ __forceinline__ double inv_norm(double s) { return s > 1e-200 ? rsqrt(s) : 0.0; }
+
 // ------------------------------------------------------------------------------------------
 // restricted targets (lane layout, D components in registers)
 //   make(cf, x, u, lvl, fresh)  coefficients of the circle through x along u; returns the level
@@ -373,13 +377,13 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             dr.block(0u, u_thr, u_th0);
         }
         {  // u = spherical_projection(z, x), sphere.py:29-33, with reciprocals instead of divisions
-            const double rnx = 1.0 / (sqrt(vdot<V>(cur.x, cur.x)) + 1e-100);
+            const double rnx = inv_norm(vdot<V>(cur.x, cur.x));
             double cz = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) cz = fma(cur.u[j], cur.x[j] * rnx, cz);
 #pragma unroll
             for (int j = 0; j < D; ++j) cur.u[j] = fma(-cz, cur.x[j] * rnx, cur.u[j]);
-            const double rnw = 1.0 / (sqrt(vdot<V>(cur.u, cur.u)) + 1e-100);
+            const double rnw = inv_norm(vdot<V>(cur.u, cur.u));
 #pragma unroll
             for (int j = 0; j < D; ++j) cur.u[j] *= rnw;
         }
@@ -806,11 +810,11 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
             dr.block(0u, u_thr, u_th0);
         }
         {   // u = spherical_projection(z, x)   (sphere.py:29-33)
-            const double rnx = 1.0 / (sqrt(vdot<V>(x, x)) + 1e-100);
+            const double rnx = inv_norm(vdot<V>(x, x));
             const double cz = vdot<V>(u, x) * rnx;
 #pragma unroll
             for (int i = 0; i < V::N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);
-            const double rnw = 1.0 / (sqrt(vdot<V>(u, u)) + 1e-100);
+            const double rnw = inv_norm(vdot<V>(u, u));
 #pragma unroll
             for (int i = 0; i < V::N; ++i) u[i] *= rnw;
         }
