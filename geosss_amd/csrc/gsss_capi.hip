@@ -105,6 +105,66 @@ __global__ void __launch_bounds__(kBlock) transpose_kernel(const double *__restr
     }
 }
 
+// 16-byte variant of the tile transpose for even R, C and 16-byte aligned buffers: every lane moves
+// a double2 on both sides (1 KiB per wave-instruction), the tile is transposed on its way INTO LDS.
+__global__ void __launch_bounds__(kBlock) transpose_kernel_x2(const double *__restrict__ in, double *__restrict__ out,
+                                                              int64_t R, int64_t C)
+{
+    __shared__ double tileT[kTile][kTile + 2];  // [column][row], row stride 66 doubles keeps 16-B alignment
+    const int64_t gx = (C + kTile - 1) / kTile;
+    const int64_t r0 = ((int64_t)blockIdx.x / gx) * kTile, c0 = ((int64_t)blockIdx.x % gx) * kTile;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
+    for (int i = ty; i < kTile; i += 8) {
+        const int64_t r = r0 + i, c = c0 + 2 * tx;
+        if (r < R && c < C) {  // C even: c + 1 < C too
+            const double2 v = *reinterpret_cast<const double2 *>(in + r * C + c);
+            tileT[2 * tx][i] = v.x;
+            tileT[2 * tx + 1][i] = v.y;
+        }
+    }
+    __syncthreads();
+    for (int j = ty; j < kTile; j += 8) {
+        const int64_t c = c0 + j, r = r0 + 2 * tx;
+        if (c < C && r < R) {
+            const double2 v = *reinterpret_cast<const double2 *>(&tileT[j][2 * tx]);
+            *reinterpret_cast<double2 *>(out + c * R + r) = v;
+        }
+    }
+}
+
+// Skinny matrices (one side <= 32, e.g. [n][3] <-> [3][n]): a 64x64 tile would be mostly empty.
+// A workgroup moves 256 indices of the long side x all S of the short side through LDS so that
+// the side that is contiguous in memory is read / written as one linear, fully coalesced run.
+constexpr int kSkinny = 32;
+
+template <bool SHORT_ROWS>
+__global__ void __launch_bounds__(kBlock) transpose_skinny_kernel(const double *__restrict__ in,
+                                                                  double *__restrict__ out, int64_t R, int64_t C)
+{
+    __shared__ double buf[kBlock * (kSkinny + 1)];
+    const int S = (int)(SHORT_ROWS ? R : C);           // short side
+    const int64_t Lg = SHORT_ROWS ? C : R;              // long side
+    const int SP = S | 1;                               // odd LDS stride: conflict-free
+    const int64_t l0 = (int64_t)blockIdx.x * kBlock;
+    const int nl = (int)((Lg - l0) < kBlock ? (Lg - l0) : kBlock);
+    const int tid = threadIdx.x;
+    if (SHORT_ROWS) {
+        // in[r][l] coalesced along l; out[l][r]: one contiguous run of nl*S doubles
+        if (tid < nl)
+            for (int r = 0; r < S; ++r) buf[tid * SP + r] = in[(int64_t)r * C + l0 + tid];
+        __syncthreads();
+        double *dst = out + l0 * S;
+        for (int k = tid; k < nl * S; k += kBlock) dst[k] = buf[(k / S) * SP + (k % S)];
+    } else {
+        // in[l][c]: one contiguous run of nl*S doubles; out[c][l] coalesced along l
+        const double *src = in + l0 * S;
+        for (int k = tid; k < nl * S; k += kBlock) buf[(k / S) * SP + (k % S)] = src[k];
+        __syncthreads();
+        if (tid < nl)
+            for (int c = 0; c < S; ++c) out[(int64_t)c * R + l0 + tid] = buf[tid * SP + c];
+    }
+}
+
 static int transpose(const double *in, double *out, int64_t R, int64_t C, int device, hipStream_t st)
 {
     if (R <= 0 || C <= 0) return GSSS_OK;
@@ -114,12 +174,32 @@ static int transpose(const double *in, double *out, int64_t R, int64_t C, int de
     }
     DeviceGuard guard(device);
     if (!guard.ok) return GSSS_E_HIP;
+    if (R <= kSkinny || C <= kSkinny) {
+        const bool short_rows = R <= C;
+        const int64_t longside = short_rows ? C : R;
+        const int64_t grid = (longside + kBlock - 1) / kBlock;
+        if (grid > 0x7FFFFFFFll) {
+            set_error("transpose: %lld x %lld exceeds the grid", (long long)R, (long long)C);
+            return GSSS_E_UNSUPPORTED;
+        }
+        if (short_rows)
+            hipLaunchKernelGGL(transpose_skinny_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, st, in, out, R, C);
+        else
+            hipLaunchKernelGGL(transpose_skinny_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, in, out, R, C);
+        GSSS_HIP_TRY(hipGetLastError());
+        return GSSS_OK;
+    }
     const int64_t gx = (C + kTile - 1) / kTile, gy = (R + kTile - 1) / kTile;
     if (gx * gy > 0x7FFFFFFFll) {
         set_error("transpose: %lld x %lld exceeds the grid", (long long)R, (long long)C);
         return GSSS_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(gx * gy)), dim3(kBlock), 0, st, in, out, R, C);
+    const bool wide = (R % 2 == 0) && (C % 2 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if (wide)
+        hipLaunchKernelGGL(transpose_kernel_x2, dim3((unsigned)(gx * gy)), dim3(kBlock), 0, st, in, out, R, C);
+    else
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(gx * gy)), dim3(kBlock), 0, st, in, out, R, C);
     GSSS_HIP_TRY(hipGetLastError());
     return GSSS_OK;
 }
