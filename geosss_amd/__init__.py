@@ -7,13 +7,13 @@ Drop-in for the slice-sampler path of microscopic-image-analysis/geosss:
     samples = gs.ShrinkageSphericalSliceSampler(pdf, init_state, seed).sample(n_samples, burnin)
 """
 from . import _lib, sphere
-from .distributions import (Bingham, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
+from .distributions import (Bingham, BinghamFisher, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
                             brownian_curve, random_bingham)
 from .mcmc import RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, determine_burnin
 from .sphere import sample_sphere, sample_sphere_device
 from .utils import SamplerLauncher, count_calls, counter
 
-__all__ = ["Bingham", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
+__all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
            "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
            "sphere"]

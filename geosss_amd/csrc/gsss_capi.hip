@@ -304,6 +304,10 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
             return GSSS_E_INVALID;
         }
         blob.assign(desc->A, desc->A + (size_t)d * d);
+        if (desc->mu)  // BinghamFisher: linear term b
+            blob.insert(blob.end(), desc->mu, desc->mu + d);
+        else
+            blob.insert(blob.end(), (size_t)d, 0.0);
         break;
     case GSSS_CURVE_VMF: {
         if (k < 2 || !desc->knots) {

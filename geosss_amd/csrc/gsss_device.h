@@ -295,13 +295,22 @@ struct VmfMixture {
 template <class V>
 struct Bingham {
     const double *A;  // LDS [d][DPAD]: rows of A, columns zero padded
+    const double *b;  // LDS [DPAD]: BinghamFisher linear term (zeros for a plain Bingham)
     int d;
-    __host__ __device__ static size_t lds_doubles(int /*k*/, int d) { return (size_t)d * V::DPAD; }
+    __host__ __device__ static size_t lds_doubles(int /*k*/, int d) { return (size_t)(d + 1) * V::DPAD; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         d = tb.d;
-        lds_fill(lds, tb.d, V::DPAD, tb.blob, tb.d);
+        lds_fill(lds, tb.d + 1, V::DPAD, tb.blob, tb.d);  // blob = A rows followed by b
         A = lds;
+        b = lds + (size_t)tb.d * V::DPAD;
+    }
+    __device__ __forceinline__ double linear(const double (&y)[V::N], int g) const
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) s = fma(y[i], b[V::comp(g, i)], s);
+        return s;  // partial over this lane's slots
     }
     // sum_j (sum_i y_i A_ij) y_j
     __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double *scratch) const
@@ -315,7 +324,7 @@ struct Bingham {
                 for (int i = 0; i < V::N; ++i) xa = fma(y[i], A[i * V::DPAD + j], xa);
                 s = fma(xa, y[j], s);
             }
-            return s;
+            return s + linear(y, g);
         } else {
             // publish y to the group's LDS row, then every lane forms (yA)_j for its own slots j
 #pragma unroll
@@ -333,6 +342,7 @@ struct Bingham {
             }
 #pragma unroll
             for (int j = 0; j < V::N; ++j) s = fma(xa[j], y[j], s);
+            s += linear(y, g);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             return V::reduce(s);

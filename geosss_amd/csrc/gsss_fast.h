@@ -108,27 +108,31 @@ template <int D>
 struct FastBingham {
     static constexpr bool kLinear = false;
     const double *A;  // LDS [D][D]
+    const double *b;  // LDS [D]: BinghamFisher linear term (zeros for a plain Bingham)
     struct Coef {
-        double qxx, qxu, quu;
+        double qxx, qxu, quu, bx, bu;
         template <class F>
         __device__ __forceinline__ void each(F &&f)
         {
             f(qxx);
             f(qxu);
             f(quu);
+            f(bx);
+            f(bu);
         }
     };
-    static constexpr int kCoefWords = 3;
-    __host__ __device__ static size_t lds_doubles() { return (size_t)D * D; }
+    static constexpr int kCoefWords = 5;
+    __host__ __device__ static size_t lds_doubles() { return (size_t)D * D + D; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
-        for (int i = threadIdx.x; i < D * D; i += kBlock) lds[i] = tb.blob[i];
+        for (int i = threadIdx.x; i < D * D + D; i += kBlock) lds[i] = tb.blob[i];
         A = lds;
+        b = lds + D * D;
     }
     __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D], double /*lvl*/,
                                            bool /*fresh*/) const
     {
-        double qxx = 0.0, qxu = 0.0, quu = 0.0;
+        double qxx = 0.0, qxu = 0.0, quu = 0.0, bx = 0.0, bu = 0.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             double xa = 0.0, ua = 0.0;  // (x A)_j, (u A)_j  (distributions.py:86 contracts rows first)
@@ -141,15 +145,20 @@ struct FastBingham {
             qxx = fma(xa, x[j], qxx);
             qxu = fma(xa, u[j], fma(ua, x[j], qxu));  // xAu + uAx (A need only be symmetric to rounding)
             quu = fma(ua, u[j], quu);
+            bx = fma(b[j], x[j], bx);
+            bu = fma(b[j], u[j], bu);
         }
         cf.qxx = qxx;
         cf.qxu = qxu;
         cf.quu = quu;
-        return qxx;
+        cf.bx = bx;
+        cf.bu = bu;
+        return qxx + bx;
     }
+    // y^T A y + y.b on the circle (distributions.py:86, :113-114)
     __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
     {
-        return fma(c * c, cf.qxx, fma(c * s, cf.qxu, (s * s) * cf.quu));
+        return fma(c * c, cf.qxx, fma(c * s, cf.qxu, (s * s) * cf.quu)) + fma(c, cf.bx, s * cf.bu);
     }
 };
 

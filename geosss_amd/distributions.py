@@ -24,7 +24,7 @@ from scipy.special import i0, ive
 from . import _lib
 from .sphere import _device_index, current_stream_ptr
 
-__all__ = ["Distribution", "VonMisesFisher", "MixtureModel", "Bingham", "CurvedVonMisesFisher", "SlerpCurve",
+__all__ = ["Distribution", "VonMisesFisher", "MixtureModel", "Bingham", "BinghamFisher", "CurvedVonMisesFisher", "SlerpCurve",
            "random_bingham", "brownian_curve", "counted"]
 
 
@@ -96,11 +96,15 @@ class Distribution:
 
     def _device_target(self, device=None):
         dev = _device_index(device)
+        kind, d, k, kappa, arrays = self._pack()
+        # the parameter attributes are public and mutable, as in the reference: key the device copy on
+        # their current bytes so that an edited target is re-uploaded instead of silently reused
+        key = (kind, d, k, kappa) + tuple(a.tobytes() if a is not None else None for a in arrays)
         cache = self.__dict__.setdefault("_targets", {})
-        if dev not in cache:
-            kind, d, k, kappa, arrays = self._pack()
-            cache[dev] = _DeviceTarget(arrays, kind, d, k, kappa, dev)
-        return cache[dev]
+        hit = cache.get(dev)
+        if hit is None or hit[0] != key:
+            cache[dev] = (key, _DeviceTarget(arrays, kind, d, k, kappa, dev))
+        return cache[dev][1]
 
     def _invalidate(self):
         self.__dict__.pop("_targets", None)
@@ -239,6 +243,27 @@ class Bingham(Distribution):
 
     def gradient(self, x):
         return 2 * self.A @ x
+
+
+class BinghamFisher(Bingham):
+    """Fisher-Bingham: log_prob = x^T A x + x.b  (distributions.py:106-114)."""
+
+    def __init__(self, A, b):
+        super().__init__(A)
+        b = np.array(b, dtype=np.float64)
+        if b.shape != (len(self.A),):
+            raise ValueError("b must have one entry per dimension")  # distributions.py:109
+        self.b = b
+
+    def _pack(self):
+        return _lib.BINGHAM, self.d, 0, 0.0, (_as_f64(self.b), None, _as_f64(self.A), None)
+
+    @counted
+    def log_prob(self, x):
+        return self._log_prob_device(x)
+
+    def gradient(self, x):
+        return 2 * self.A @ x + self.b
 
 
 def random_bingham(d=2, vmax=None, vmin=None, eigensystem=False, seed=None):

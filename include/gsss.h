@@ -66,7 +66,8 @@ typedef struct gsss_target gsss_target; /* opaque; owns a small device parameter
  *   VMF_MIXTURE: k components on S^{d-1}.  mu[k][d] = kappa_k * direction_k exactly as
  *       VonMisesFisher stores it (distributions.py:126-127);  logc[k] = log(w_k) - log(2 pi)
  *       - log(i0(|mu_k|)) = the x-independent part of distributions.py:157 and :220.
- *   BINGHAM:     A[d][d] symmetric (distributions.py:67-70).
+ *   BINGHAM:     A[d][d] symmetric (distributions.py:67-70); if mu is non-NULL it is the vector b[d] of a
+ *       BinghamFisher target, log_prob = x^T A x + x.b (distributions.py:106-114).
  *   CURVE_VMF:   knots[k][d] unit vectors, kappa (distributions.py:263-265).
  */
 typedef struct gsss_target_desc {

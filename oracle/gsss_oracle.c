@@ -17,7 +17,7 @@
  *   gor_distance_slerp          geosss/spherical_curve.py:10-32
  *   gor_find_nearest            geosss/spherical_curve.py:95-102
  *   gor_logprob (vMF mixture)   geosss/distributions.py:156-157, 218-221
- *   gor_logprob (Bingham)       geosss/distributions.py:78-86
+ *   gor_logprob (Bingham)       geosss/distributions.py:78-86 (+ BinghamFisher :106-114)
  *   gor_logprob (curve vMF)     geosss/distributions.py:272-275
  *   gor_step (shrink)           geosss/mcmc.py:382-401
  *   gor_step (reject)           geosss/mcmc.py:357-374
@@ -63,6 +63,7 @@ typedef struct {
     const double *lognorm; /* [k]     log(2 pi) + log(i0(|mu_k|))   (distributions.py:157) */
     const double *logw;    /* [k]     log of the normalised weights (distributions.py:213-220) */
     const double *A;       /* [d][d]  Bingham precision (distributions.py:70) */
+    const double *b;       /* [d] or NULL: BinghamFisher linear term (distributions.py:106-114) */
     const double *knots;   /* [k][d]  SlerpCurve knots (spherical_curve.py:37,79) */
     double kappa;          /* curve concentration (distributions.py:265) */
 } gor_target;
@@ -183,6 +184,7 @@ double gor_logprob(const gor_target *t, const double *x)
             for (int i = 0; i < d; ++i) xa += x[i] * t->A[(size_t)i * d + j];
             s += xa * x[j];
         }
+        if (t->b) s += gor_dot(x, t->b, d); /* distributions.py:113-114 */
         return s;
     }
     if (t->kind == GOR_CURVE_VMF) {

@@ -28,7 +28,7 @@ def build(force=False):
 class _Target(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("k", C.c_int32),
                 ("mu", C.c_void_p), ("lognorm", C.c_void_p), ("logw", C.c_void_p),
-                ("A", C.c_void_p), ("knots", C.c_void_p), ("kappa", C.c_double)]
+                ("A", C.c_void_p), ("b", C.c_void_p), ("knots", C.c_void_p), ("kappa", C.c_double)]
 
 
 _lib = None
@@ -63,16 +63,17 @@ def log_i0(kappa):
 class Target:
     """Plain-array description of a target + the C struct the oracle reads."""
 
-    def __init__(self, kind, d, k=0, mu=None, lognorm=None, logw=None, A=None, knots=None, kappa=0.0):
+    def __init__(self, kind, d, k=0, mu=None, lognorm=None, logw=None, A=None, knots=None, kappa=0.0, b=None):
         self.kind, self.d, self.k = kind, int(d), int(k)
         self.mu = _f64(mu) if mu is not None else None
         self.lognorm = _f64(lognorm) if lognorm is not None else None
         self.logw = _f64(logw) if logw is not None else None
         self.A = _f64(A) if A is not None else None
         self.knots = _f64(knots) if knots is not None else None
+        self.b = _f64(b) if b is not None else None
         self.kappa = float(kappa)
         self.c = _Target(kind, self.d, self.k, _p(self.mu), _p(self.lognorm), _p(self.logw), _p(self.A),
-                         _p(self.knots), self.kappa)
+                         _p(self.b), _p(self.knots), self.kappa)
 
     @classmethod
     def vmf_mixture(cls, mu, weights=None):
@@ -84,9 +85,9 @@ class Target:
         return cls(VMF_MIXTURE, d, k, mu=mu, lognorm=lognorm, logw=np.log(w))
 
     @classmethod
-    def bingham(cls, A):
+    def bingham(cls, A, b=None):
         A = _f64(A)
-        return cls(BINGHAM, A.shape[0], A=A)
+        return cls(BINGHAM, A.shape[0], A=A, b=b)
 
     @classmethod
     def curve_vmf(cls, knots, kappa):
@@ -99,7 +100,7 @@ class Target:
         if kind == "vmf_mixture":
             return cls.vmf_mixture(z[prefix + "mu"], z[prefix + "weights"])
         if kind == "bingham":
-            return cls.bingham(z[prefix + "A"])
+            return cls.bingham(z[prefix + "A"], z[prefix + "b"] if prefix + "b" in z.files else None)
         if kind == "curve_vmf":
             return cls.curve_vmf(z[prefix + "knots"], float(z[prefix + "kappa"]))
         raise ValueError(kind)

@@ -143,6 +143,8 @@ def target_params(pdf):
     if isinstance(pdf, gs.MixtureModel):
         mu = np.array([p.mu for p in pdf.pdfs])
         return dict(kind="vmf_mixture", mu=mu, weights=np.array(pdf.weights))
+    if isinstance(pdf, gs.BinghamFisher):  # distributions.py:106-114
+        return dict(kind="bingham", A=np.array(pdf.A, dtype=float), b=np.array(pdf.b, dtype=float))
     if isinstance(pdf, gs.Bingham):
         return dict(kind="bingham", A=np.array(pdf.A))
     if isinstance(pdf, CurvedVonMisesFisher):
@@ -178,6 +180,12 @@ def cases():
     out["bingham_d5_dense"] = (b5, gs.sphere.sample_sphere(4, seed=6), 81, 300)
     b50 = gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=True, seed=6982)
     out["bingham_d50_vmax300"] = (b50, np.array(b50.mode), 82, 150)
+    # tests/test_bingham_fisher.py:20-35 (Byrne & Girolami / Brubaker et al. examples)
+    bf5 = gs.BinghamFisher(np.diag([-20.0, -10.0, 0.0, 10.0, 20.0]), np.array([40.0, 0.0, 0.0, 0.0, 0.0]))
+    out["binghamfisher_d5"] = (bf5, gs.sphere.sample_sphere(4, seed=7), 83, 300)
+    bf6 = gs.BinghamFisher(np.diag([-1000.0, -600.0, -200.0, 200.0, 600.0, 1000.0]),
+                           np.array([100.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+    out["binghamfisher_d6"] = (bf6, gs.sphere.sample_sphere(5, seed=8), 84, 300)
     for d, kappa, n in ((3, 300.0, 300), (10, 800.0, 300), (10, 500.0, 200), (24, 800.0, 150),
                         (50, 800.0, 150), (200, 800.0, 100)):
         out[f"curve_d{d}_kappa{int(kappa)}"] = (
@@ -195,13 +203,17 @@ def flat_params(p):
     return {f"target_{k}": (np.array(v) if not isinstance(v, str) else np.array(v)) for k, v in p.items()}
 
 
-def make_trajectories():
+def make_trajectories(only=None):
     for name, (pdf, x0, seed, n) in cases().items():
+        if only and name not in only:
+            continue
         t0 = time.time()
         rec = record_trajectory(gs.ShrinkageSphericalSliceSampler, pdf, x0, seed, n)
         print(f"{name}: {n} steps, rej/step={rec['n_reject'] / n:.3f}, "
               f"min margin={rec['min_margin']:.3e}, {time.time() - t0:.1f}s")
         save(f"traj_{name}.npz", x0=np.array(x0), sampler=np.array("shrink"), **flat_params(target_params(pdf)), **rec)
+    if only:
+        return
     # rejection sampler (mcmc.py:357-374): README target and the small Bingham
     for name, n in (("vmfmix_readme", 60), ("bingham_d10_vmax30", 150)):
         pdf, x0, seed, _ = cases()[name]
@@ -348,6 +360,9 @@ if __name__ == "__main__":
         make_timing()
     if "traj" in what:
         make_trajectories()
+    only = [w[5:] for w in what if w.startswith("only:")]
+    if only:
+        make_trajectories(only)
     if "logprob" in what:
         make_logprob_kat()
     if "geometry" in what:

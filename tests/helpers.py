@@ -11,6 +11,8 @@ def product_target(z, prefix="target_"):
     if kind == "vmf_mixture":
         return gs.MixtureModel([gs.VonMisesFisher(m) for m in z[prefix + "mu"]], z[prefix + "weights"])
     if kind == "bingham":
+        if prefix + "b" in z.files:
+            return gs.BinghamFisher(z[prefix + "A"], z[prefix + "b"])
         return gs.Bingham(z[prefix + "A"])
     if kind == "curve_vmf":
         return gs.CurvedVonMisesFisher(gs.SlerpCurve(z[prefix + "knots"]), float(z[prefix + "kappa"]))
@@ -38,7 +40,7 @@ def pad_replay(draws, offsets):
 
 # shapes the GSSS_MODE_FAST kernels are built for (geosss_amd/csrc/gsss_fast_*.hip)
 FAST_VMF = {(3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 10), (4, 4), (10, 5)}
-FAST_BINGHAM = {3, 4, 5, 10}
+FAST_BINGHAM = {3, 4, 5, 6, 10}
 FAST_CURVE = {(3, 10), (6, 10), (10, 10), (12, 10), (24, 10)}  # (d, knots)
 
 
