@@ -174,10 +174,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; GSSS_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the
+    # multi-rank code path on a single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("GSSS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import geosss_amd as gs
     from geosss_amd.ensemble import gather_states
@@ -200,6 +207,8 @@ def main():
 
     for _ in range(args.warmup):
         sampler.advance(S, thin=thin, out=kept)
+    if world > 1:  # the collective's lazy channel setup must not land inside the timed region
+        gather_states(sampler.state_device)
     tries0 = int(sampler._n_tries.sum().item())
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
