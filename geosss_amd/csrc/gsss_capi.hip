@@ -440,6 +440,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     rb.n_tries = a->n_tries_dev;
     rb.err = a->err_dev;
     rb.replay = a->replay_dev;
+    rb.rng_state = a->rng_state_dev;
     rb.replay_stride = a->replay_stride;
     rb.n_chains = a->n_chains;
     rb.n_steps = a->n_steps;
@@ -453,6 +454,15 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool replay = a->replay_dev != nullptr;
+    if (replay && a->rng_state_dev) {
+        set_error("replay_dev and rng_state_dev are mutually exclusive");
+        return GSSS_E_INVALID;
+    }
+    if (a->rng_state_dev && a->mode == GSSS_MODE_FAST) {
+        set_error("the numpy stream is served by the exact kernels only (mode = GSSS_MODE_EXACT)");
+        return GSSS_E_UNSUPPORTED;
+    }
+    const int draws = replay ? kDrawsReplay : (a->rng_state_dev ? kDrawsNumpy : kDrawsPhilox);
     if (a->mode == GSSS_MODE_FAST) {
         if (a->n_steps > 0x7FFFFFFFll || a->thin > 0x7FFFFFFFll || a->n_chains > 0x7FFFFFFFll - 1024 ||
             a->replay_stride > 0x7FFFFFFFll) {
@@ -462,9 +472,9 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         return fast_dispatch(t->tb, rb, replay, false, st);
     }
     switch (t->tb.kind) {
-    case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, replay, t->tb, rb, st);
-    case GSSS_BINGHAM: return launch_run<Bingham>(vec, replay, t->tb, rb, st);
-    case GSSS_CURVE_VMF: return launch_run<CurveVmf>(vec, replay, t->tb, rb, st);
+    case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, draws, t->tb, rb, st);
+    case GSSS_BINGHAM: return launch_run<Bingham>(vec, draws, t->tb, rb, st);
+    case GSSS_CURVE_VMF: return launch_run<CurveVmf>(vec, draws, t->tb, rb, st);
     }
     set_error("corrupt target");
     return GSSS_E_INVALID;

@@ -35,6 +35,7 @@ struct RunBlock {
     int64_t *n_tries;
     int32_t *err;
     const double *replay;
+    uint64_t *rng_state;  // numpy stream: [n_chains][4] PCG64 words (state_hi, state_lo, inc_hi, inc_lo)
     int64_t replay_stride;
     int64_t n_chains, n_steps, thin;
     uint64_t seed, chain_offset, step_offset;
@@ -130,6 +131,9 @@ __device__ __forceinline__ double vdot(const double (&a)[V::N], const double (&b
 template <class V>
 struct PhiloxDraws {
     static constexpr bool kReplay = false;
+    static constexpr int kLdsDoubles = 0;
+    __device__ __forceinline__ void stage(double *) {}
+    __device__ __forceinline__ void finish(const RunBlock &, int64_t, bool) const {}
     uint32_t k0, k1, c1, c2, c3, chain_hi;
     int d, t;
     double cached;
@@ -197,6 +201,9 @@ struct PhiloxDraws {
 template <class V>
 struct ReplayDraws {
     static constexpr bool kReplay = true;
+    static constexpr int kLdsDoubles = 0;
+    __device__ __forceinline__ void stage(double *) {}
+    __device__ __forceinline__ void finish(const RunBlock &, int64_t, bool) const {}
     const double *p;
     int64_t len, cur;
     int d;
@@ -240,6 +247,124 @@ struct ReplayDraws {
         u_theta0 = need_theta0 ? take() : 0.0;
     }
     __device__ __forceinline__ double next_try() { return take(); }
+};
+
+// numpy's own stream: PCG64 (XSL-RR 128/64) + Generator.random / uniform / standard_normal, so that
+// a chain seeded like the reference (np.random.default_rng(seed), geosss/mcmc.py:45) consumes the very
+// numbers the reference consumes (mcmc.py:387, 389, 391, 395).  Sequential per chain by nature: every
+// lane of a cooperative group runs the identical generator and keeps the components it owns.
+#define NPY_ZIG_NOR_R 3.6541528853610087963519472518
+#define NPY_ZIG_NOR_INV_R 0.27366123732975827203338247596
+__device__ const uint64_t kNpyKi[256] = {
+#define NPY_ZIG_ONLY_KI
+#include "numpy_ziggurat_tables.inc"
+#undef NPY_ZIG_ONLY_KI
+};
+__device__ const double kNpyWi[256] = {
+#define NPY_ZIG_ONLY_WI
+#include "numpy_ziggurat_tables.inc"
+#undef NPY_ZIG_ONLY_WI
+};
+__device__ const double kNpyFi[256] = {
+#define NPY_ZIG_ONLY_FI
+#include "numpy_ziggurat_tables.inc"
+#undef NPY_ZIG_ONLY_FI
+};
+
+template <class V>
+struct NumpyDraws {
+    static constexpr bool kReplay = false;
+    static constexpr int kLdsDoubles = 768;
+    uint64_t sh, sl, ih, il;
+    const double *wi, *fi;
+    const uint64_t *ki;
+    int d;
+    bool exhausted;
+
+    __device__ __forceinline__ void stage(double *lds)
+    {
+        uint64_t *k = reinterpret_cast<uint64_t *>(lds);
+        for (int i = threadIdx.x; i < 256; i += kBlock) {
+            k[i] = kNpyKi[i];
+            lds[256 + i] = kNpyWi[i];
+            lds[512 + i] = kNpyFi[i];
+        }
+        ki = k;
+        wi = lds + 256;
+        fi = lds + 512;
+    }
+    __device__ __forceinline__ void init(const RunBlock &a, int64_t chain_local, int d_)
+    {
+        const uint64_t *w = a.rng_state + 4 * chain_local;
+        sh = w[0];
+        sl = w[1];
+        ih = w[2];
+        il = w[3];
+        d = d_;
+        exhausted = false;
+    }
+    __device__ __forceinline__ void finish(const RunBlock &a, int64_t chain_local, bool store) const
+    {
+        if (!store) return;
+        uint64_t *w = a.rng_state + 4 * chain_local;
+        w[0] = sh;
+        w[1] = sl;
+    }
+    __device__ __forceinline__ void begin_step(uint64_t) {}
+    __device__ __forceinline__ uint64_t next64()
+    {
+        constexpr uint64_t MH = 2549297995355413924ull, ML = 4865540595714422341ull;
+        // (sh:sl) = (sh:sl) * (MH:ML) + (ih:il)  mod 2^128
+        const uint64_t lo = sl * ML;
+        uint64_t hi = __umul64hi(sl, ML) + sl * MH + sh * ML;
+        const uint64_t nlo = lo + il;
+        hi += ih + (nlo < lo ? 1ull : 0ull);
+        sl = nlo;
+        sh = hi;
+        const uint64_t x = sh ^ sl;
+        const unsigned rot = (unsigned)(sh >> 58);
+        return (x >> rot) | (x << ((64u - rot) & 63u));
+    }
+    __device__ __forceinline__ double next_double() { return (double)(next64() >> 11) * 0x1.0p-53; }
+    __device__ double standard_normal()
+    {
+        for (;;) {
+            uint64_t r = next64();
+            const int idx = (int)(r & 0xff);
+            r >>= 8;
+            const bool neg = r & 1;
+            const uint64_t rabs = (r >> 1) & 0x000fffffffffffffull;
+            double x = (double)rabs * wi[idx];
+            if (neg) x = -x;
+            if (rabs < ki[idx]) return x;
+            if (idx == 0) {
+                for (;;) {
+                    const double xx = -NPY_ZIG_NOR_INV_R * log1p(-next_double());
+                    const double yy = -log1p(-next_double());
+                    if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(NPY_ZIG_NOR_R + xx) : NPY_ZIG_NOR_R + xx;
+                }
+            } else if (((fi[idx - 1] - fi[idx]) * next_double() + fi[idx]) < exp(-0.5 * x * x)) {
+                return x;
+            }
+        }
+    }
+    __device__ __forceinline__ void normals(double (&z)[V::N], int g)
+    {
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) z[i] = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double v = standard_normal();
+#pragma unroll
+            for (int i = 0; i < V::N; ++i)
+                if (V::comp(g, i) == c) z[i] = v;
+        }
+    }
+    __device__ __forceinline__ void step_uniforms(double &u_thr, double &u_theta0, bool need_theta0)
+    {
+        u_thr = next_double();
+        u_theta0 = need_theta0 ? next_double() : 0.0;
+    }
+    __device__ __forceinline__ double next_try() { return next_double(); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -426,6 +551,8 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
     T tgt;
     tgt.stage(lds, tb);
     double *scratch = lds + T::lds_doubles(tb.k, tb.d) + (size_t)T::kScratchPerChain * (threadIdx.x / V::L);
+    Draws dr;
+    dr.stage(lds + T::lds_doubles(tb.k, tb.d) + scratch_doubles<V, T>());
     __syncthreads();
 
     const int d = tb.d;
@@ -441,7 +568,6 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
         const int cc = V::comp(g, i);
         x[i] = (cc < d) ? a.state[(size_t)cc * n + c] : 0.0;
     }
-    Draws dr;
     dr.init(a, c, d);
 
     double px = tgt.logp(x, g, scratch);
@@ -547,6 +673,7 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
             if (a.err && err) a.err[c] |= err;
         }
     }
+    dr.finish(a, c, active && g == 0);
 }
 
 // Distribution.log_prob for rows of a row-major [n][d] array

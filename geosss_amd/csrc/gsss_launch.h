@@ -45,8 +45,11 @@ const VecInfo *vec_table(int *count);
 // id of the layout used for dimension d (variant == 0) or validation of a forced one; <0 on error
 int select_vec(int d, int variant);
 
+// draw source of a launch
+enum : int { kDrawsPhilox = 0, kDrawsReplay = 1, kDrawsNumpy = 2 };
+
 template <template <class> class TT>
-int launch_run(int vec_id, bool replay, const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
+int launch_run(int vec_id, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
 template <template <class> class TT>
 int launch_logprob(int vec_id, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st);
 
@@ -65,7 +68,7 @@ template <class V, template <class> class TT, template <class> class DR>
 int do_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
     using T = TT<V>;
-    const size_t lds = (T::lds_doubles(tb.k, tb.d) + scratch_doubles<V, T>()) * sizeof(double);
+    const size_t lds = (T::lds_doubles(tb.k, tb.d) + scratch_doubles<V, T>() + DR<V>::kLdsDoubles) * sizeof(double);
     if (lds > kMaxLdsBytes) {
         set_error("target parameters need %zu B of LDS (> %zu)", lds, kMaxLdsBytes);
         return GSSS_E_UNSUPPORTED;
@@ -104,7 +107,7 @@ int do_logprob(const TargetBlock &tb, const double *x, int64_t n, double *out, h
 // Each target's translation unit expands this once.
 #define GSSS_DEFINE_TARGET_LAUNCHERS(TT)                                                                      \
     template <>                                                                                               \
-    int launch_run<TT>(int vec_id, bool replay, const TargetBlock &tb, const RunBlock &rb, hipStream_t st)     \
+    int launch_run<TT>(int vec_id, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st)       \
     {                                                                                                         \
         switch (vec_id) {                                                                                     \
             GSSS_VEC_LIST(GSSS_RUN_CASE_##TT)                                                                  \

@@ -12,10 +12,16 @@ geosss/mcmc.py for the two slice samplers:
 convention the reference's harness feeds to its ESS estimator.
 
 All transitions run in the HIP kernels behind `gsss_run` (include/gsss.h); chain states stay
-resident in HBM between calls.  Random numbers come from the library's counter-based stream
-(DESIGN.md "RNG stream"), keyed by `seed`, chain id and step id, so results do not depend on how
-chains are split over devices or steps over calls.  `sampler.rng` is kept as a numpy Generator for
-API compatibility but the kernels do not draw from it.
+resident in HBM between calls.  Two random streams:
+
+  rng="philox" (default)  the library's counter-based stream (DESIGN.md "RNG stream"), keyed by
+      `seed`, chain id and step id: results do not depend on how chains are split over devices or
+      steps over calls; this is the throughput path.
+  rng="numpy"             numpy's own PCG64 + ziggurat stream restated on the device: a chain seeded
+      like the reference (`np.random.default_rng(seed)`, mcmc.py:45) consumes exactly the numbers
+      the reference consumes, so `Sampler(pdf, x0, seed).sample(n, burnin)` reproduces geosss's
+      output from the seed alone (to rounding, ~1e-14).  For one chain `sampler.rng` is kept in
+      step with the device stream, as the reference's attribute would be.
 """
 import ctypes as C
 
@@ -69,12 +75,18 @@ class RejectionSphericalSliceSampler:
     _sampler = _lib.REJECT
 
     def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="auto", max_tries=None,
-                 chain_offset=0, step_offset=0, variant=0):
+                 chain_offset=0, step_offset=0, variant=0, rng="philox"):
         _lib.require_device()
         self._lib = _lib.load()
         self.target = distribution
-        self.rng = np.random.default_rng(seed if not isinstance(seed, np.random.Generator) else None)
-        self.seed = seed_to_key(seed)
+        if rng not in ("philox", "numpy"):
+            raise ValueError("rng must be 'philox' or 'numpy'")
+        self.rng_kind = rng
+        self._seed_arg = seed
+        many_seeds = isinstance(seed, (list, tuple))
+        self.rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(
+            seed[0] if many_seeds else seed)
+        self.seed = 0 if rng == "numpy" else seed_to_key(seed[0] if many_seeds else seed)
         self.device = _device_index(device)
         self._tdev = f"cuda:{self.device}"
         self.mode = mode
@@ -85,6 +97,10 @@ class RejectionSphericalSliceSampler:
         self.variant = int(variant)
         self._step = int(step_offset)
         self._target_dev = distribution._device_target(self.device)
+        if rng == "numpy":
+            if mode == "fast":
+                raise ValueError("the numpy stream is served by the exact kernels (mode='exact' or 'auto')")
+            mode = self.mode = "exact"
         if mode == "auto":  # the throughput kernels where they are built for this shape, else the generic ones
             fast_ok = self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST) and not variant
             self.mode = "fast" if fast_ok else "exact"
@@ -94,6 +110,42 @@ class RejectionSphericalSliceSampler:
         self._n_tries = torch.zeros(n, dtype=torch.int64, device=self._tdev)
         self._err = torch.zeros(n, dtype=torch.int32, device=self._tdev)
         self._tries_reported = 0
+        self._rng_state = self._numpy_states(seed) if rng == "numpy" else None
+
+    def _numpy_states(self, seed):
+        """[n_chains, 4] PCG64 words (state_hi, state_lo, inc_hi, inc_lo), one default_rng per chain:
+        the sampler's own generator for a single chain; for many chains the given list of seeds, or
+        SeedSequence(seed).spawn(n_chains) (the pattern of scripts/bingham.py:87-88)."""
+        n = self.n_chains
+        if n == 1:
+            gens = [self.rng]
+        elif isinstance(seed, (list, tuple)):
+            if len(seed) != n:
+                raise ValueError("one seed per chain")
+            gens = [s if isinstance(s, np.random.Generator) else np.random.default_rng(s) for s in seed]
+        else:
+            root = seed if isinstance(seed, np.random.SeedSequence) else np.random.SeedSequence(seed)
+            gens = [np.random.default_rng(s) for s in root.spawn(n)]
+        words = np.empty((n, 4), dtype=np.uint64)
+        mask = (1 << 64) - 1
+        for i, g in enumerate(gens):
+            bg = g.bit_generator
+            if not isinstance(bg, np.random.PCG64):
+                raise TypeError("rng='numpy' restates numpy's default PCG64 bit generator")
+            st = bg.state["state"]
+            words[i] = [st["state"] >> 64, st["state"] & mask, st["inc"] >> 64, st["inc"] & mask]
+        return torch.from_numpy(words.view(np.int64)).to(self._tdev)
+
+    def _sync_rng(self):
+        """One chain: put the device stream's position back into `self.rng` (what the reference's
+        sampler.rng would hold after the same calls)."""
+        if self._rng_state is None or self.n_chains != 1:
+            return
+        w = self._rng_state.cpu().numpy().view(np.uint64)[0]
+        st = self.rng.bit_generator.state
+        st["state"] = {"state": (int(w[0]) << 64) | int(w[1]), "inc": (int(w[2]) << 64) | int(w[3])}
+        st["has_uint32"], st["uinteger"] = 0, 0
+        self.rng.bit_generator.state = st
 
     # ------------------------------------------------------------------ state handling
     def _set_state(self, x):
@@ -197,6 +249,10 @@ class RejectionSphericalSliceSampler:
         a.mode = _MODES[self.mode]
         a.max_tries = min(self.max_tries, 2**31 - 1)
         a.variant = self.variant
+        if self._rng_state is not None:
+            if replay is not None:
+                raise ValueError("replay and rng='numpy' are mutually exclusive")
+            a.rng_state_dev = self._rng_state.data_ptr()
         _lib.check(self._lib.gsss_run(self._target_dev.handle, C.byref(a), self._stream()))
         self._step += int(n_steps)
 
@@ -255,6 +311,7 @@ class RejectionSphericalSliceSampler:
         self.advance(1)
         self._account_calls(1)
         self._check_errors()
+        self._sync_rng()
         return self.state
 
     def sample(self, n_samples, burnin=0, return_all_samples=False, *, thin=1, as_tensor=False):
@@ -282,6 +339,7 @@ class RejectionSphericalSliceSampler:
                                                     self.device, self._stream()))
         self._account_calls(self._step - steps0)
         self._check_errors()
+        self._sync_rng()
         if self._single:
             out = out[0]
         return out if as_tensor else out.cpu().numpy()

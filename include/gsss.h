@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 1
+#define GSSS_ABI_VERSION 2
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -93,7 +93,8 @@ typedef struct gsss_target_desc {
  * (DESIGN.md "RNG stream").  If replay_dev is non-NULL the draws are read from it instead:
  * per chain `replay_stride` doubles in the order the reference consumes them
  * (d normals, u_threshold, [u_theta0,] u_try, u_try, ... ; next step ...) -- this is how the
- * parity tests reproduce reference chains bit for bit.
+ * parity tests reproduce reference chains bit for bit.  A third source, rng_state_dev, is numpy's
+ * own PCG64 + ziggurat stream restated on the device: `seed -> chain` exactly as in the reference.
  */
 typedef struct gsss_run_args {
     double *state_dev;         /* [d][n_chains] in/out                                             */
@@ -113,6 +114,10 @@ typedef struct gsss_run_args {
     int32_t mode;              /* GSSS_MODE_EXACT | GSSS_MODE_FAST */
     int32_t max_tries;         /* > 0: give up a step after this many proposals */
     int32_t variant;           /* 0 = library's choice; otherwise a kernel variant id (gsss_variant_name) */
+    uint64_t *rng_state_dev;   /* [n_chains][4] or NULL.  Non-NULL selects NUMPY'S OWN STREAM instead of Philox: per chain the
+                                  PCG64 words (state_hi, state_lo, inc_hi, inc_lo) of np.random.default_rng(seed).bit_generator,
+                                  read at entry and written back at exit, so a chain consumes exactly the numbers the reference's
+                                  sampler.rng would (mcmc.py:45, 387-395).  GSSS_MODE_EXACT only; `seed`/offsets are then unused */
 } gsss_run_args;
 
 int gsss_abi_version(void);

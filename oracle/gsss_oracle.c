@@ -34,15 +34,21 @@
  *   scipy.special.i0                         -> NOT restated: log i0(kappa_k) is an
  *       x-independent constant; the Python side passes it in (`lognorm`), computed with
  *       scipy exactly as distributions.py:157 does.
- *   numpy PCG64/ziggurat                     -> NOT restated: draws are either replayed from
- *       a recorded stream (bit parity with the reference chain) or come from the
- *       counter-based Philox4x32-10 stream specified in DESIGN.md "RNG stream", which the
- *       HIP kernels implement identically (integer part bit-exact).
+ *   numpy PCG64/ziggurat (numpy 2.2.6)       -> three draw sources: (1) replay of a recorded
+ *       stream (bit parity with the reference chain); (2) the counter-based Philox4x32-10 stream
+ *       specified in DESIGN.md "RNG stream", which the HIP kernels implement identically; (3) numpy's
+ *       own stream restated -- PCG64 XSL-RR 128/64 (numpy/random/src/pcg64/pcg64.h) feeding
+ *       Generator.random / uniform / standard_normal (256-block ziggurat of
+ *       numpy/random/src/distributions/distributions.c, tables read out of the installed numpy by
+ *       tools/extract_numpy_ziggurat.py) -- so that `default_rng(seed)` chains are reproduced from
+ *       the seed alone; tests/test_numpy_stream.py matches it against numpy bit for bit.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include "numpy_ziggurat_tables.h"
 
 #define GOR_VMF_MIXTURE 1
 #define GOR_BINGHAM 2
@@ -265,7 +271,73 @@ static void gor_box_muller32(uint32_t wr, uint32_t wa, double *z0, double *z1)
     *z1 = r * sin(ang);
 }
 
+/* ---- numpy's PCG64 (XSL-RR 128/64, setseq) and the distributions built on it ---- */
 typedef struct {
+    unsigned __int128 state, inc;
+} gor_pcg64;
+
+static uint64_t gor_pcg64_next64(gor_pcg64 *g)
+{
+    const unsigned __int128 mult = ((unsigned __int128)2549297995355413924ULL << 64) | 4865540595714422341ULL;
+    g->state = g->state * mult + g->inc; /* step, then output the NEW state */
+    uint64_t hi = (uint64_t)(g->state >> 64), lo = (uint64_t)g->state;
+    uint64_t x = hi ^ lo;
+    unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+static double gor_npy_double(gor_pcg64 *g) { return (double)(gor_pcg64_next64(g) >> 11) * (1.0 / 9007199254740992.0); }
+
+/* random_standard_normal of numpy's distributions.c */
+static double gor_npy_standard_normal(gor_pcg64 *g)
+{
+    for (;;) {
+        uint64_t r = gor_pcg64_next64(g);
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 0x1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * NPY_ZIG_WI[idx];
+        if (sign & 0x1) x = -x;
+        if (rabs < NPY_ZIG_KI[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -NPY_ZIG_NOR_INV_R * log1p(-gor_npy_double(g));
+                double yy = -log1p(-gor_npy_double(g));
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 0x1) ? -(NPY_ZIG_NOR_R + xx) : NPY_ZIG_NOR_R + xx;
+            }
+        } else {
+            if (((NPY_ZIG_FI[idx - 1] - NPY_ZIG_FI[idx]) * gor_npy_double(g) + NPY_ZIG_FI[idx]) < exp(-0.5 * x * x))
+                return x;
+        }
+    }
+}
+
+/* test hooks: fill arrays from a PCG64 state given as (state_hi, state_lo, inc_hi, inc_lo) */
+static void gor_pcg_load(gor_pcg64 *g, const uint64_t *w)
+{
+    g->state = ((unsigned __int128)w[0] << 64) | w[1];
+    g->inc = ((unsigned __int128)w[2] << 64) | w[3];
+}
+static void gor_pcg_store(const gor_pcg64 *g, uint64_t *w)
+{
+    w[0] = (uint64_t)(g->state >> 64);
+    w[1] = (uint64_t)g->state;
+    w[2] = (uint64_t)(g->inc >> 64);
+    w[3] = (uint64_t)g->inc;
+}
+void gor_npy_fill(uint64_t *pcg, int64_t n_normal, double *normals, int64_t n_uniform, double *uniforms)
+{
+    gor_pcg64 g;
+    gor_pcg_load(&g, pcg);
+    for (int64_t i = 0; i < n_normal; ++i) normals[i] = gor_npy_standard_normal(&g);
+    for (int64_t i = 0; i < n_uniform; ++i) uniforms[i] = gor_npy_double(&g);
+    gor_pcg_store(&g, pcg);
+}
+
+typedef struct {
+    /* numpy stream */
+    gor_pcg64 *pcg;
     /* replay */
     const double *replay;
     int64_t replay_len, cursor;
@@ -290,6 +362,10 @@ static double gor_take(gor_draws *g)
 static void gor_draw_normals(gor_draws *g, double *z)
 {
     int d = g->d;
+    if (g->pcg) {
+        for (int i = 0; i < d; ++i) z[i] = gor_npy_standard_normal(g->pcg);
+        return;
+    }
     if (g->replay) {
         for (int i = 0; i < d; ++i) z[i] = gor_take(g);
         return;
@@ -307,6 +383,11 @@ static void gor_draw_normals(gor_draws *g, double *z)
 /* the threshold uniform (mcmc.py:389) and theta0 uniform (mcmc.py:391) */
 static void gor_draw_step_uniforms(gor_draws *g, double *u_thr, double *u_theta0, int need_theta0)
 {
+    if (g->pcg) {
+        *u_thr = gor_npy_double(g->pcg);
+        *u_theta0 = need_theta0 ? gor_npy_double(g->pcg) : 0.0;
+        return;
+    }
     if (g->replay) {
         *u_thr = gor_take(g);
         *u_theta0 = need_theta0 ? gor_take(g) : 0.0;
@@ -321,6 +402,7 @@ static void gor_draw_step_uniforms(gor_draws *g, double *u_thr, double *u_theta0
 /* the uniform of try number `g->try_idx` (mcmc.py:395) */
 static double gor_draw_try(gor_draws *g)
 {
+    if (g->pcg) return gor_npy_double(g->pcg);
     if (g->replay) return gor_take(g);
     int64_t t = g->try_idx++;
     if (t & 1) return g->cached;
@@ -397,13 +479,15 @@ static int gor_step(const gor_target *t, double *x, gor_draws *g, int sampler, i
  *   n_reject, n_tries [n_chains] are ADDED to; err [n_chains] is OR-ed into
  *   replay     [n_chains][replay_stride] recorded draws in consumption order, or NULL
  *   thr_trace  [n_chains][n_steps] or NULL
+ *   pcg_state  [n_chains][4] or NULL: numpy PCG64 (state_hi, state_lo, inc_hi, inc_lo) per chain,
+ *              in/out -- draws then come from numpy's own stream (default_rng semantics)
  * chain ids are chain_offset + i, step ids step_offset + s (the RNG counter), so any
  * partition of chains / steps over calls or devices gives the same numbers.
  */
 int gor_run(const gor_target *t, double *state, int64_t n_chains, int64_t n_steps, int64_t thin, uint64_t seed,
             uint64_t chain_offset, uint64_t step_offset, int sampler, int64_t max_tries, double *samples,
             int64_t *n_reject, int64_t *n_tries, int32_t *err, const double *replay, int64_t replay_stride,
-            double *thr_trace, int n_threads)
+            double *thr_trace, int n_threads, uint64_t *pcg_state)
 {
     int d = t->d;
     if (thin < 1) thin = 1;
@@ -424,6 +508,11 @@ int gor_run(const gor_target *t, double *state, int64_t n_chains, int64_t n_step
             g.replay = replay + (size_t)c * replay_stride;
             g.replay_len = replay_stride;
         }
+        gor_pcg64 pcg;
+        if (pcg_state) {
+            gor_pcg_load(&pcg, pcg_state + 4 * c);
+            g.pcg = &pcg;
+        }
         for (int64_t s = 0; s < n_steps; ++s) {
             g.step = step_offset + (uint64_t)s;
             int64_t tries = 0;
@@ -438,6 +527,7 @@ int gor_run(const gor_target *t, double *state, int64_t n_chains, int64_t n_step
             }
             if (e) break;
         }
+        if (pcg_state) gor_pcg_store(&pcg, pcg_state + 4 * c);
         free(scratch);
     }
     return 0;

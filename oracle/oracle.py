@@ -114,8 +114,27 @@ class Target:
         return out
 
 
+def pcg64_words(seed):
+    """(state_hi, state_lo, inc_hi, inc_lo) of np.random.default_rng(seed)'s PCG64, one row per seed."""
+    seeds = seed if isinstance(seed, (list, tuple)) else [seed]
+    out = np.empty((len(seeds), 4), dtype=np.uint64)
+    for i, sd in enumerate(seeds):
+        st = np.random.default_rng(sd).bit_generator.state["state"]
+        m = (1 << 64) - 1
+        out[i] = [st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m]
+    return out
+
+
+def npy_fill(pcg_words, n_normal, n_uniform):
+    """Draw n_normal standard normals then n_uniform uniforms from the restated numpy stream."""
+    w = np.array(pcg_words, dtype=np.uint64).reshape(4).copy()
+    z, u = np.empty(n_normal), np.empty(n_uniform)
+    lib().gor_npy_fill(_p(w), C.c_int64(n_normal), _p(z), C.c_int64(n_uniform), _p(u))
+    return z, u, w
+
+
 def run(target, state, n_steps, seed=0, chain_offset=0, step_offset=0, sampler=SHRINK, thin=1, max_tries=100000,
-        keep_samples=True, replay=None, trace_threshold=False, n_threads=1):
+        keep_samples=True, replay=None, trace_threshold=False, n_threads=1, numpy_seed=None):
     """Advance every row of `state` (n_chains, d) by n_steps transitions.
 
     Returns dict(state, samples (n_chains, n_keep, d) | None, n_reject, n_tries, err, threshold).
@@ -139,12 +158,16 @@ def run(target, state, n_steps, seed=0, chain_offset=0, step_offset=0, sampler=S
             replay = replay[None]
         assert replay.shape[0] == n
         stride = replay.shape[1]
+    pcg = None
+    if numpy_seed is not None:  # numpy's own stream: one default_rng(seed) per chain
+        pcg = pcg64_words(numpy_seed if isinstance(numpy_seed, (list, tuple)) else [numpy_seed])
+        assert len(pcg) == n
     lib().gor_run(C.byref(target.c), _p(state), C.c_int64(n), C.c_int64(n_steps), C.c_int64(thin),
                   C.c_uint64(seed), C.c_uint64(chain_offset), C.c_uint64(step_offset), C.c_int(sampler),
                   C.c_int64(max_tries), _p(samples), _p(n_reject), _p(n_tries), _p(err), _p(replay),
-                  C.c_int64(stride), _p(thr), C.c_int(n_threads))
+                  C.c_int64(stride), _p(thr), C.c_int(n_threads), _p(pcg))
     return dict(state=state[0] if single else state, samples=samples, n_reject=n_reject, n_tries=n_tries, err=err,
-                threshold=thr)
+                threshold=thr, pcg=pcg)
 
 
 def sample_sphere(seed, n, d, chain_offset=0):

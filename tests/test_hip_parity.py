@@ -281,3 +281,56 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
     lp = pdf.log_prob(kept[:, -1])
     ref = tgt.log_prob(kept[:, -1])
     assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
+
+
+# ------------------------------------------------------------------ numpy's own stream on the device
+
+
+def test_readme_call_from_seed(gs):
+    """README.md:44-64 verbatim with rng='numpy': ShrinkageSphericalSliceSampler(pdf, init, 3521)
+    .sample(1000, 100) equals the reference's output, n_reject and num_calls, from the seed alone."""
+    z, t = golden("readme_sample_call.npz"), golden("traj_vmfmix_readme.npz")
+    pdf = product_target(t)
+    type(pdf).log_prob.reset_counters()
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.array([-0.86, 0.19, -0.47]), 3521, rng="numpy")
+    out = s.sample(1000, 100)
+    assert out.shape == (1000, 3)
+    assert np.max(np.abs(out - z["samples"])) < TOL
+    assert s.n_reject == int(z["n_reject"])
+    assert pdf.log_prob.num_calls == int(z["num_calls"])
+    # sampler.rng sits where the reference's generator would: both continue identically
+    ref = np.random.default_rng(3521)
+    ref.bit_generator.state = s.rng.bit_generator.state
+    nxt = next(s)
+    assert s.rng.random() != ref.random()  # the device consumed the draws of one more step
+    assert nxt.shape == (3,)
+
+
+@pytest.mark.parametrize("name", trajectory_names("shrink") + trajectory_names("reject"))
+def test_reference_chain_from_seed(gs, name):
+    """Every golden reference chain reproduced on the GPU from (pdf, x0, seed) alone."""
+    z = golden(name + ".npz")
+    pdf = product_target(z)
+    cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
+    s = cls(pdf, z["x0"], int(z["seed"]), rng="numpy")
+    n = len(z["states"]) - 1
+    out = s.sample(n + 1)
+    assert np.array_equal(out[0], z["x0"])
+    assert np.max(np.abs(out - z["states"])) < TOL
+    assert s.n_reject == int(z["n_reject"])
+
+
+def test_numpy_stream_many_chains(gs, oracle):
+    """One default_rng per chain (SeedSequence.spawn, scripts/bingham.py:87-88): device = oracle's numpy
+    stream; cooperative layouts run the identical generator on every lane of a group."""
+    z = golden("traj_curve_d50_kappa800.npz")
+    pdf, tgt = product_target(z), oracle.Target.from_fixture(z)
+    seeds = list(np.random.SeedSequence(48385).spawn(37))
+    x0 = oracle.sample_sphere(2, 37, 50)
+    want = oracle.run(tgt, x0, 15, numpy_seed=seeds)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, np.random.SeedSequence(48385), rng="numpy")
+    got = s.advance(15, thin=1).permute(2, 0, 1).cpu().numpy()
+    assert np.max(np.abs(got - want["samples"])) < TOL
+    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, rng="numpy", mode="fast")
