@@ -126,27 +126,23 @@ def numpy_port_baseline(workload, cores, n_steps=400):
             "sample": f"{n_steps} steps per chain, one chain per process"}
 
 
-def ess_per_sec(gs, pdf, d, seed, steps_per_sec_per_chain_total, n_chains=512, n_draws=4000):
+def ess_per_sec(gs, pdf, d, seed, steps_per_sec_total, n_chains=512, n_draws=4000):
     """Effective samples per second (secondary metric): mean over a chain subsample of
-    n_eff = n / IAT of the first coordinate (IAT estimated by the initial-positive-sequence
-    rule on the FFT autocorrelation, the estimator family of geosss/utils.py:109-134), scaled to
-    the measured whole-job step rate."""
-    import torch
+    n_eff / n for the first coordinate with the reference's own estimator (geosss/utils.py:119-134,
+    restated batched in geosss_amd/diagnostics.py and run on the GPU), scaled to the measured
+    whole-job step rate; plus the mode occupancy of the same draws."""
     x0 = gs.sample_sphere_device(d - 1, n_chains, seed=1).T
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed)
     s.advance(200)
-    X = s.sample(n_draws, as_tensor=True)[:, :, 0]               # (chains, draws)
-    X = X - X.mean(dim=1, keepdim=True)
-    n = X.shape[1]
-    f = torch.fft.rfft(X, n=2 * n, dim=1)
-    acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=1)[:, :n]
-    acf = acf / acf[:, :1]
-    pair = acf[:, 0:n - 1:2] + acf[:, 1:n:2]                      # Geyer: sums of adjacent pairs
-    positive = torch.cumprod((pair > 0).to(torch.float64), dim=1)
-    iat = torch.clamp(2.0 * (pair * positive).sum(dim=1) - 1.0, min=1.0)
-    rel = float((1.0 / iat).mean().item())                         # ESS per step
-    return {"ess_per_step": rel, "ess_per_sec": rel * steps_per_sec_per_chain_total,
-            "estimator": f"first coordinate, Geyer initial positive sequence, {n_chains} chains x {n_draws} draws"}
+    X = s.sample(n_draws, as_tensor=True)                          # (chains, draws, dims), on the device
+    rel = float((gs.diagnostics.n_eff(X[:, :, 0]) / n_draws).mean().item())
+    out = {"ess_per_step": rel, "ess_per_sec": rel * steps_per_sec_total,
+           "estimator": f"geosss IAT heuristic on the first coordinate, {n_chains} chains x {n_draws} draws"}
+    if isinstance(pdf, gs.MixtureModel):
+        import torch
+        modes = torch.as_tensor(np.array([p.mu for p in pdf.pdfs]), device=X.device)
+        out["mode_occupancy"] = [float(v) for v in gs.diagnostics.mode_occupancy(X, modes).cpu()]
+    return out
 
 
 def main():

@@ -6,7 +6,8 @@ Drop-in for the slice-sampler path of microscopic-image-analysis/geosss:
     pdf = gs.MixtureModel([gs.VonMisesFisher(80.0 * mu) for mu in mus])
     samples = gs.ShrinkageSphericalSliceSampler(pdf, init_state, seed).sample(n_samples, burnin)
 """
-from . import _lib, sphere
+from . import _lib, diagnostics, sphere
+from .diagnostics import IAT, acf, acf_fft, distance, n_eff
 from .distributions import (Bingham, BinghamFisher, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
                             brownian_curve, random_bingham)
 from .mcmc import RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, determine_burnin
@@ -16,4 +17,4 @@ from .utils import SamplerLauncher, count_calls, counter
 __all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
            "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
-           "sphere"]
+           "sphere", "diagnostics", "IAT", "acf", "acf_fft", "distance", "n_eff"]

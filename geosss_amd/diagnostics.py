@@ -1,0 +1,103 @@
+"""Chain diagnostics with the reference's definitions, batched over chains and device-resident.
+
+    acf, acf_fft, IAT, n_eff      geosss/utils.py:96-134
+    distance                      geosss/sphere.py:64-68
+    hopping_frequency             scripts/bingham.py:23-25
+    mode_occupancy, mode_kl       scripts/vMF_diagnostics.py:335-342
+
+Inputs may be numpy arrays or torch tensors (CPU or GPU); the time axis is the last-but-one for
+sample arrays (..., n_draws, d) and the last one for scalar series (..., n_draws), so a whole
+(chains, draws, dims) ensemble from `sampler.sample(..., as_tensor=True)` is analysed without leaving
+the GPU.  One scalar series gives the reference's scalar.
+"""
+import numpy as np
+import torch
+
+__all__ = ["acf", "acf_fft", "IAT", "n_eff", "distance", "hopping_frequency", "mode_occupancy", "mode_kl"]
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float64))
+
+
+def _back(y, like):
+    if isinstance(like, torch.Tensor):
+        return y
+    y = y.cpu().numpy()
+    return y.item() if y.ndim == 0 else y
+
+
+def acf_fft(x):
+    """Autocorrelation by the convolution theorem, lags 0 .. n//2-1 (utils.py:113-116), along the last axis."""
+    t = _t(x).to(torch.float64)
+    n = t.shape[-1]
+    z = (t - t.mean(-1, keepdim=True)) / t.std(-1, unbiased=False, keepdim=True)
+    f = torch.fft.rfft(z, dim=-1)
+    # like np.fft.irfft without `n`: the inverse has 2*(len(f)-1) points (n-1 for odd n), as in the reference
+    ac = torch.fft.irfft(f.conj() * f, n=2 * (f.shape[-1] - 1), dim=-1)[..., : n // 2] / n
+    return _back(ac, x)
+
+
+def acf(x, n_max=None):
+    """Direct autocorrelation estimate for lags < n_max (utils.py:96-110), along the last axis."""
+    t = _t(x).to(torch.float64)
+    n = t.shape[-1]
+    n_max = n_max or n // 2
+    z = t - t.mean(-1, keepdim=True)
+    ac = torch.stack([(z[..., i:] * z[..., : n - i]).mean(-1) for i in range(n_max)], dim=-1)
+    return _back(ac / ac[..., :1], x)
+
+
+def IAT(x, n=None):
+    """Integrated autocorrelation time by the heuristic of utils.py:119-131: adjacent-pair sums of the
+    autocorrelation from lag 2, truncated at the first negative pair."""
+    ac = _t(acf_fft(_t(x)))
+    if n:
+        ac = ac[..., :n]
+    m = ac.shape[-1]
+    tail = ac[..., 2:-1] if m % 2 != 0 else ac[..., 2:]
+    sums = tail.reshape(*tail.shape[:-1], -1, 2).sum(-1)
+    neg = sums < 0
+    has = neg.any(-1)
+    first = torch.argmax(neg.to(torch.int64), dim=-1)                 # index of the first negative pair
+    L = torch.where(has, 1 + 2 * first, torch.full_like(first, m - 1))
+    lag = torch.arange(m, device=ac.device)
+    keep = (lag >= 1) & (lag <= L.unsqueeze(-1))
+    s = (ac * keep).sum(-1)
+    return _back(1.0 + torch.clamp(2.0 * s, min=0.0), x)
+
+
+def n_eff(x, n=None):
+    """Effective sample size len(x) / IAT(x) (utils.py:132-134)."""
+    t = _t(x)
+    return _back(t.shape[-1] / _t(IAT(t, n)), x)
+
+
+def distance(x, y):
+    """Great-circle distance arccos(clip(x.y, -1, 1)) (sphere.py:64-68)."""
+    a, b = _t(x).to(torch.float64), _t(y).to(torch.float64)
+    return _back(torch.arccos(torch.clamp((a * b).sum(-1), -1.0, 1.0)), x)
+
+
+def hopping_frequency(samples, mode):
+    """Fraction of consecutive draws on opposite sides of the mode's equator (scripts/bingham.py:23-25);
+    samples (..., n_draws, d)."""
+    s = _t(samples).to(torch.float64)
+    side = torch.sign(s @ _t(mode).to(s))
+    return _back((side[..., 1:] != side[..., :-1]).to(torch.float64).mean(-1), samples)
+
+
+def mode_occupancy(samples, modes):
+    """Share of draws whose nearest mode (largest x.mu_k) is k; samples (..., d) flattened."""
+    s = _t(samples).to(torch.float64).reshape(-1, _t(samples).shape[-1])
+    k = torch.argmax(s @ _t(modes).to(s).T, dim=1)
+    occ = torch.bincount(k, minlength=len(modes)).to(torch.float64) / len(k)
+    return _back(occ, samples)
+
+
+def mode_kl(occupancy, weights):
+    """KL(occupancy || weights) with the reference's 1e-100 floor for empty modes."""
+    p = _t(occupancy).to(torch.float64)
+    p = torch.where(p > 0, p, torch.full_like(p, 1e-100))
+    w = _t(weights).to(p)
+    return _back((p * torch.log(p / w)).sum(), occupancy)

@@ -354,10 +354,44 @@ def make_timing():
         json.dump(out, f, indent=1)
 
 
+def make_diagnostics():
+    """Known answers of the reference's diagnostics (utils.py:96-134 acf/acf_fft/IAT/n_eff,
+    sphere.py:64-68 distance, scripts/bingham.py:23-25 hopping frequency, the mode-occupancy KL of
+    scripts/vMF_diagnostics.py:335-342) on reference chains."""
+    from geosss.utils import IAT, acf, acf_fft, n_eff
+    pdf, x0, seed, _ = cases()["vmfmix_readme"]
+    X = gs.ShrinkageSphericalSliceSampler(pdf, np.array(x0), 11).sample(4001)
+    arrays = {"vmf_X": X}
+    arrays["vmf_acf_fft"] = np.array([acf_fft(X[:, j]) for j in range(3)])
+    arrays["vmf_acf"] = np.array([acf(X[:, j], 50) for j in range(3)])
+    arrays["vmf_IAT"] = np.array([IAT(X[:, j]) for j in range(3)])
+    arrays["vmf_IAT_200"] = np.array([IAT(X[:, j], 200) for j in range(3)])
+    arrays["vmf_n_eff"] = np.array([n_eff(X[:, j]) for j in range(3)])
+    arrays["vmf_distance"] = rsphere.distance(X[1:], X[:-1])
+    modes = np.array([p.mu for p in pdf.pdfs])
+    m = np.argmax(X @ modes.T, axis=1)
+    i, c = np.unique(m, return_counts=True)
+    p = np.full(len(modes), 1e-100)
+    p[i] = c
+    p[i] /= p.sum()
+    arrays["vmf_modes"] = modes
+    arrays["vmf_occupancy"] = p
+    arrays["vmf_kl"] = p @ np.log(p / pdf.weights)
+    b10, xb, _, _ = cases()["bingham_d10_vmax30"]
+    Xb = gs.ShrinkageSphericalSliceSampler(b10, np.array(xb), 12).sample(3000)
+    arrays["bingham_X"] = Xb
+    arrays["bingham_mode"] = np.array(b10.mode)
+    arrays["bingham_hop"] = np.mean(np.diff(np.sign(Xb @ b10.mode)) != 0.0)
+    arrays["bingham_IAT"] = np.array([IAT(Xb[:, j]) for j in range(10)])
+    save("diagnostics_kat.npz", **arrays)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing"]
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics"]
     if "timing" in what:
         make_timing()
+    if "diagnostics" in what:
+        make_diagnostics()
     if "traj" in what:
         make_trajectories()
     only = [w[5:] for w in what if w.startswith("only:")]
