@@ -411,8 +411,8 @@ struct VmfMixture {
         for (int k = 0; k < K; ++k) amax = fmax(amax, comp_logp(y, g, k));
         if (!(amax > -INFINITY) || amax == INFINITY) return amax;
         double s = 0.0;
-        for (int k = 0; k < K; ++k) s += exp(comp_logp(y, g, k) - amax);
-        return amax + log(s);
+        for (int k = 0; k < K; ++k) s += fm::exp_fast(comp_logp(y, g, k) - amax);
+        return amax + fm::log_fast(s);
     }
     static constexpr int kScratchPerChain = 0;
 };
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
         }
         double u_thr, u_th0;
         dr.step_uniforms(u_thr, u_th0, shrink);
-        const double thr = px + log(u_thr);  // mcmc.py:389
+        const double thr = px + fm::log_fast(u_thr);  // mcmc.py:389
         double lo, hi;
         if (shrink) {
             hi = kTwoPi * u_th0;             // mcmc.py:391
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
             }
             const double theta = lo + (hi - lo) * dr.next_try();  // mcmc.py:395
             double sn, cs;
-            sincos(theta, &sn, &cs);
+            fm::sincos_small(theta, sn, cs);  // |theta| <= 2 pi by construction of the bracket
             double y[V::N];
 #pragma unroll
             for (int i = 0; i < V::N; ++i) y[i] = fma(sn, u[i], cs * x[i]);  // mcmc.py:396
