@@ -84,7 +84,7 @@ struct FastVmf {
         }
         // the offset m only keeps the exponentials in range; re-centre it when the carried level
         // has drifted far from 1 (or on the first step of a launch)
-        if (fresh || !(lvl > 1e-150 && lvl < 1e150)) {
+        if (kScreened || fresh || !(lvl > 1e-150 && lvl < 1e150)) {
             double m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + logc[k]);
@@ -95,12 +95,45 @@ struct FastVmf {
         }
         return lvl;
     }
-    __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
+    // Many components: only the largest term is exponentiated in double; the others are bounded from
+    // above with the hardware's single-precision 2^x.  lower = e^{a_max-m} <= S <= lower (1 + r_ub), and
+    // the accept test S > thr is decided by the bounds whenever thr is outside (lower, upper] -- the same
+    // decision the full sum gives.  Otherwise (thr between the bounds: the other components matter, rare
+    // for separated modes) the full double-precision sum is formed.  Returns a value that compares with
+    // `thr` exactly like the full sum; the level carried to the next step is recomputed in make().
+    static constexpr bool kScreened = KC >= 5;
+    __device__ __forceinline__ double level_full(const double (&a)[KC]) const
     {
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; ++k) sum += fm::exp_bounded(fma(c, cf.ax[k], fma(s, cf.au[k], logc[k])) - cf.m);
+        for (int k = 0; k < KC; ++k) sum += fm::exp_bounded(a[k]);
         return sum;
+    }
+    __device__ __forceinline__ double level(const Coef &cf, double c, double s, double thr) const
+    {
+        double a[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) a[k] = fma(c, cf.ax[k], fma(s, cf.au[k], logc[k])) - cf.m;
+        if (!kScreened) return level_full(a);
+        double amax = a[0];
+#pragma unroll
+        for (int k = 1; k < KC; ++k) amax = fmax(amax, a[k]);
+        const double lower = fm::exp_bounded(amax);
+        float r = -1.0f;  // sum_k 2^{(a_k - amax) log2 e} - 1 : the terms other than the largest
+#pragma unroll
+        for (int k = 0; k < KC; ++k) r += __builtin_amdgcn_exp2f((float)(a[k] - amax) * 1.44269504f);
+        const double r_ub = (double)fmaxf(r, 0.0f) * 1.0001 + 2e-6;  // covers the float exp, cast and sum errors
+        if (lower > thr) return lower;                                // S >= lower > thr: accept
+        const double upper = lower * (1.0 + r_ub);
+        if (upper <= thr) return upper;                               // S <= upper <= thr: reject
+        return level_full(a);
+    }
+    __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
+    {
+        double a[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) a[k] = fma(c, cf.ax[k], fma(s, cf.au[k], logc[k])) - cf.m;
+        return level_full(a);
     }
 };
 
@@ -155,6 +188,10 @@ struct FastBingham {
         cf.bu = bu;
         return qxx + bx;
     }
+    __device__ __forceinline__ double level(const Coef &cf, double c, double s, double /*thr*/) const
+    {
+        return level(cf, c, s);
+    }
     // y^T A y + y.b on the circle (distributions.py:86, :113-114)
     __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
     {
@@ -200,6 +237,10 @@ struct FastCurve {
     //   t = 0 when B <= 0,  t = th when A < cos(th) hypot(A, B),  else sin t = B/h, cos t = A/h,
     // and y . near = (sin(th - t) (a.y) + sin(t) (b.y)) / (sin(th) + 1e-10).  The nearest segment is
     // the first one of minimal acos(clip(y.near)) = the first one of maximal clipped y.near.
+    __device__ __forceinline__ double level(const Coef &cf, double c, double s, double /*thr*/) const
+    {
+        return level(cf, c, s);
+    }
     __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
     {
         double best = -INFINITY, best_dot = 0.0;
@@ -439,7 +480,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
                 const double theta = fma(cur.hi - cur.lo, uu, cur.lo);  // mcmc.py:395
                 ++cur.t;
                 fm::sincos_small(theta, sn, cs);
-                lvl = tp.level(cur.cf, cs, sn);
+                lvl = tp.level(cur.cf, cs, sn, cur.thr);
                 accepted = lvl > cur.thr;                               // mcmc.py:397
                 if (!accepted && shrink) {                              // mcmc.py:400
                     if (theta < 0.0)
@@ -732,7 +773,7 @@ struct CoopVmf {
     }
     __device__ __forceinline__ double level0(typename Scalar::Coef &cf, double carried, bool fresh) const
     {
-        if (fresh || !(carried > 1e-150 && carried < 1e150)) {
+        if (Scalar::kScreened || fresh || !(carried > 1e-150 && carried < 1e150)) {
             double m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + sc.logc[k]);
