@@ -228,6 +228,34 @@ class RejectionSphericalSliceSampler:
             raise _lib.GsssError(f"{bad} chain(s) stopped with error bits (max {bits}): "
                                  "1=max_tries, 2=non-finite log_prob, 4=replay exhausted")
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything needed to continue this run elsewhere (plain numpy): states, stream position,
+        counters.  The counter-based stream makes a resumed run bit-identical to an uninterrupted one."""
+        d = {"state": self.state_rows().cpu().numpy(), "step": self._step, "seed": self.seed,
+             "chain_offset": self.chain_offset, "n_reject": self.n_reject_per_chain,
+             "n_tries": self.n_tries_per_chain, "err": self.errors, "rng": self.rng_kind,
+             "sampler": self._sampler, "mode": self.mode}
+        if self._rng_state is not None:
+            d["rng_state"] = self._rng_state.cpu().numpy().view(np.uint64)
+        return d
+
+    def load_state_dict(self, d):
+        """Inverse of state_dict() on a sampler built for the same target and number of chains."""
+        if d["state"].shape != (self.n_chains, self.d) or d["rng"] != self.rng_kind:
+            raise ValueError("checkpoint does not match this sampler")
+        single = self._single
+        self._set_state(d["state"])
+        self._single = single
+        self._step, self.seed, self.chain_offset = int(d["step"]), int(d["seed"]), int(d["chain_offset"])
+        self._n_reject.copy_(torch.from_numpy(np.asarray(d["n_reject"], dtype=np.int64)))
+        self._n_tries.copy_(torch.from_numpy(np.asarray(d["n_tries"], dtype=np.int64)))
+        self._err.copy_(torch.from_numpy(np.asarray(d["err"], dtype=np.int32)))
+        self._tries_reported = int(self._n_tries.sum().item())
+        if self._rng_state is not None:
+            self._rng_state.copy_(torch.from_numpy(np.asarray(d["rng_state"], dtype=np.uint64).view(np.int64)))
+            self._sync_rng()
+
     # ------------------------------------------------------------------ running
     def _launch(self, n_steps, samples=None, thin=1, replay=None):
         a = _lib.RunArgs()

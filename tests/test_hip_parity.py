@@ -334,3 +334,43 @@ def test_numpy_stream_many_chains(gs, oracle):
     assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
     with pytest.raises(ValueError):
         gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, rng="numpy", mode="fast")
+
+
+def test_edge_shapes(gs):
+    """Empty ensemble, one chain, one draw, ragged block tails, zero steps."""
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.zeros((0, 3)), 1)
+    assert s.n_chains == 0
+    s.advance(5)
+    assert s.sample(3).shape == (0, 3, 3) and s.n_reject == 0 and s.state.shape == (0, 3)
+    assert pdf.log_prob(np.zeros((0, 3))).shape == (0,)
+    one = gs.ShrinkageSphericalSliceSampler(pdf, z["x0"], 5)
+    assert np.array_equal(one.sample(1), z["x0"][None])            # n_samples = 1: the initial state, no step
+    assert one._step == 0
+    one.advance(0)
+    for n in (1, 63, 64, 65, 511, 512, 513, 1025):                    # around wave / workgroup boundaries
+        x0 = gs.sample_sphere(2, n, seed=n).reshape(n, 3)
+        a = gs.ShrinkageSphericalSliceSampler(pdf, x0, 9, mode="fast")
+        b = gs.ShrinkageSphericalSliceSampler(pdf, x0, 9, mode="exact")
+        xa, xb = a.sample(8), b.sample(8)
+        assert xa.shape == (n, 8, 3) and np.max(np.abs(xa - xb)) < TOL
+        assert np.array_equal(a.n_reject_per_chain, b.n_reject_per_chain)
+
+
+@pytest.mark.parametrize("rng", ["philox", "numpy"])
+def test_checkpoint_resume(gs, rng):
+    """state_dict / load_state_dict: an interrupted run continues bit-identically (both streams)."""
+    z = golden("traj_bingham_d10_vmax30.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere(9, 200, seed=4)
+    ref = gs.ShrinkageSphericalSliceSampler(pdf, x0, 21, rng=rng)
+    ref.advance(30)
+    a = gs.ShrinkageSphericalSliceSampler(pdf, x0, 21, rng=rng)
+    a.advance(12)
+    ck = a.state_dict()
+    b = gs.ShrinkageSphericalSliceSampler(pdf, np.zeros_like(x0) + x0[:1], 99 if rng == "philox" else 21, rng=rng)
+    b.load_state_dict(ck)
+    b.advance(18)
+    assert np.array_equal(b.state, ref.state)
+    assert np.array_equal(b.n_reject_per_chain, ref.n_reject_per_chain) and b._step == 30

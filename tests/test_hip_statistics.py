@@ -127,3 +127,16 @@ def test_rejection_sampler_statistics(gs):
     s.advance(1)
     geo = torch.arccos(torch.clamp((s.state_rows() * prev).sum(1), -1, 1)).mean().item()
     assert abs(geo - 1.58) < 0.03, geo
+
+
+def test_eight_million_chains_one_gpu(gs):
+    """BASELINE cfg5's total ensemble (8*10^6 chains) on a single GPU: largest size, no error flags,
+    rejections/step as the reference."""
+    z, st = golden("traj_vmfmix_k10_kappa500.npz"), golden("stats_vmfmix_k10_kappa500.npz")
+    pdf = product_target(z)
+    n = 8_000_000
+    x0 = gs.sample_sphere_device(2, n, seed=3).T
+    s, rej, tries, _ = _run(gs, pdf, x0, 20, 60)
+    ref = float(st["rej_per_step"].mean())
+    assert abs(rej - ref) / ref < 0.03, (rej, ref)
+    assert s.state_device.shape == (3, n)
