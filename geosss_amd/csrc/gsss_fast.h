@@ -14,9 +14,12 @@
 //     so a try needs K exps and no log.
 //  3. Two chains per lane with deferred setup.  The number of tries per step varies (mean 5,
 //     p99 12), so a step-synchronous wavefront idles half its lanes in the shrink loop.  Here a lane
-//     that accepts switches to its second chain at once; the per-step setup (RNG, Box-Muller,
-//     projection, coefficients) runs for the whole wavefront only when enough lanes have a chain
-//     waiting for it.  Simulated lane utilisation 0.83 vs 0.49 (DESIGN.md "Scheduling").
+//     keeps one chain in registers and a second one parked in LDS; when its chain accepts it trades
+//     the two (ds_wrxchg) and keeps trying; the per-step setup (RNG, Box-Muller, projection,
+//     coefficients) runs for the whole wavefront only when enough lanes have a chain waiting for it.
+//     Measured lane utilisation 0.72 vs 0.49.
+//
+// The second half of the file holds the cooperative variant for large d (L lanes per chain).
 //
 // Elementary functions come from gsss_math.h (bounded-range sincos, Taylor exp).  Results agree
 // with the reference to ~1e-14 per step; tests hold them to 1e-10 against the golden chains.
@@ -25,7 +28,6 @@
 #include "gsss_math.h"
 
 namespace gsss {
-
 
 enum : int32_t { kReady = 0, kPending = 1, kDone = 2 };
 
