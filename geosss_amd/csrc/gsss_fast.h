@@ -254,7 +254,7 @@ struct FastCurve {
             const double A = ay * st;
             const double B = fma(-ay, ct, by);
             const double h2 = fma(A, A, B * B);
-            const double rh = h2 > 0.0 ? 1.0 / sqrt(h2) : 0.0;
+            const double rh = h2 > 0.0 ? rsqrt(h2) : 0.0;
             const double inner = fma(fma(st, A, -ct * B), ay, B * by) * rh;  // sin(th-t) a.y + sin(t) b.y
             const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
             const bool at_b = A * rh < ct;
@@ -718,7 +718,7 @@ struct CoopCurve {
         const double A = ay * m.st;
         const double B = fma(-ay, m.ct, by);
         const double h2 = fma(A, A, B * B);
-        const double rh = h2 > 0.0 ? 1.0 / sqrt(h2) : 0.0;
+        const double rh = h2 > 0.0 ? rsqrt(h2) : 0.0;
         const double inner = fma(fma(m.st, A, -m.ct * B), ay, B * by) * rh;
         const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
         const bool at_b = A * rh < m.ct;
