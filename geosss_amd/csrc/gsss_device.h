@@ -99,6 +99,52 @@ struct LaneVec {
     __device__ static __forceinline__ double reduce(double v) { return v; }
 };
 
+// ------------------------------------------------------------------------------------------
+// Cross-lane moves without LDS: DPP within a row of 16 lanes, scalar broadcasts across rows.
+// (`__shfl_xor` lowers to ds_bpermute, two LDS round trips per double; the reductions of the
+// cooperative kernels sit on the critical path of every step.)
+// ------------------------------------------------------------------------------------------
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7-i within 8
+constexpr int kDppMirror = 0x140;      // lane i <-> 15-i within 16
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_move(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ double lane_broadcast(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the L_ lanes of a group, identical bits in every lane: after the two quad steps all four
+// lanes of a quad agree, so the mirror steps add equal partners in either order (commutative)
+template <int L_>
+__device__ __forceinline__ double group_sum(double v)
+{
+    if (L_ >= 2) v += dpp_move<kDppXor1>(v);
+    if (L_ >= 4) v += dpp_move<kDppXor2>(v);
+    if (L_ >= 8) v += dpp_move<kDppHalfMirror>(v);
+    if (L_ >= 16) v += dpp_move<kDppMirror>(v);
+    if (L_ == 64) {  // the wave is one group: add the four row sums in a fixed order
+        const double r0 = lane_broadcast(v, 0), r1 = lane_broadcast(v, 16);
+        const double r2 = lane_broadcast(v, 32), r3 = lane_broadcast(v, 48);
+        v = (r0 + r1) + (r2 + r3);
+    }
+    return v;
+}
+
 template <int L_, int S_>
 struct CoopVec {
     static_assert(S_ % 4 == 0, "slots come in quads");
@@ -107,13 +153,9 @@ struct CoopVec {
     static constexpr int DPAD = L_ * S_;
     static constexpr bool kExactDim = false;  // any d <= DPAD
     __device__ static __forceinline__ int comp(int g, int i) { return 4 * (g + L_ * (i >> 2)) + (i & 3); }
-    // xor-butterfly over the L lanes of a group: every lane ends with the same bits
-    __device__ static __forceinline__ double reduce(double v)
-    {
-#pragma unroll
-        for (int m = 1; m < L_; m <<= 1) v += __shfl_xor(v, m, 64);
-        return v;
-    }
+    // sum over the L lanes of a group: every lane ends with the same bits
+    static_assert(L_ == 4 || L_ == 16 || L_ == 64, "group sizes with a DPP reduction");
+    __device__ static __forceinline__ double reduce(double v) { return group_sum<L_>(v); }
 };
 
 template <class V>

@@ -692,6 +692,7 @@ struct CoopCurve {
     // Lane g of a group evaluates segment g (lanes >= NK-1 sit out); an xor-butterfly then picks the
     // first segment of maximal clipped y.near -- the same choice as the sequential scan.
     static constexpr bool kDistributed = V::L >= 16;
+    static_assert(NK - 1 <= 16, "segments must fit one row of 16 lanes");
     struct Mine {
         double ax0, au0, ax1, au1, ct, st, rden;
     };
@@ -726,15 +727,19 @@ struct CoopCurve {
         double xy = num * m.rden;
         double xc = g < NK - 1 ? fmin(fmax(xy, -1.0), 1.0) : -INFINITY;
         int idx = g;
-#pragma unroll
-        for (int w = 1; w < V::L; w <<= 1) {
-            const double oxc = __shfl_xor(xc, w, 64), oxy = __shfl_xor(xy, w, 64);
-            const int oidx = __shfl_xor(idx, w, 64);
+        // (xc, idx) is totally ordered (larger xc first, then smaller idx): the winner of a row of 16 lanes
+        // does not depend on the order of the pairwise steps; the segments live in lanes 0 .. NK-2 of row 0
+        auto step = [&](double oxc, double oxy, int oidx) {
             const bool take = oxc > xc || (oxc == xc && oidx < idx);
             xc = take ? oxc : xc;
             xy = take ? oxy : xy;
             idx = take ? oidx : idx;
-        }
+        };
+        step(dpp_move<kDppXor1>(xc), dpp_move<kDppXor1>(xy), dpp_move<kDppXor1>(idx));
+        step(dpp_move<kDppXor2>(xc), dpp_move<kDppXor2>(xy), dpp_move<kDppXor2>(idx));
+        step(dpp_move<kDppHalfMirror>(xc), dpp_move<kDppHalfMirror>(xy), dpp_move<kDppHalfMirror>(idx));
+        step(dpp_move<kDppMirror>(xc), dpp_move<kDppMirror>(xy), dpp_move<kDppMirror>(idx));
+        if (V::L == 64) xy = lane_broadcast(xy, 0);  // one chain per wave: rows 1-3 hold no segment
         return sc.kappa * xy;
     }
     __device__ __forceinline__ double level(const typename Scalar::Coef &cf, double c, double s) const
