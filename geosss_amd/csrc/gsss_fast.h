@@ -693,25 +693,28 @@ struct CoopCurve {
     // first segment of maximal clipped y.near -- the same choice as the sequential scan.
     static constexpr bool kDistributed = V::L >= 16;
     static_assert(NK - 1 <= 16, "segments must fit one row of 16 lanes");
-    struct Mine {
+    struct Mine {  // what lane g needs of the coefficients: those of knots g and g+1 (its segment)
         double ax0, au0, ax1, au1, ct, st, rden;
     };
-    __device__ __forceinline__ Mine mine(const typename Scalar::Coef &cf, int g) const
+    __device__ __forceinline__ Mine mine_init(int g) const
     {
-        Mine m{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i + 1 < NK; ++i)
-            if (g == i) {
-                m.ax0 = cf.ax[i];
-                m.au0 = cf.au[i];
-                m.ax1 = cf.ax[i + 1];
-                m.au1 = cf.au[i + 1];
-            }
         const int gs = g < NK - 1 ? g : 0;
-        m.ct = sc.seg[4 * gs];
-        m.st = sc.seg[4 * gs + 1];
-        m.rden = sc.seg[4 * gs + 2];
-        return m;
+        return Mine{0.0, 0.0, 0.0, 0.0, sc.seg[4 * gs], sc.seg[4 * gs + 1], sc.seg[4 * gs + 2]};
+    }
+    __device__ __forceinline__ void take_au(Mine &m, int g, int r, double v) const
+    {
+        if (r == g) m.au0 = v;
+        if (r == g + 1) m.au1 = v;
+    }
+    __device__ __forceinline__ void take_ax(Mine &m, int g, int r, double v) const
+    {
+        if (r == g) m.ax0 = v;
+        if (r == g + 1) m.ax1 = v;
+    }
+    __device__ __forceinline__ void advance(Mine &m, double c, double s) const  // a.x' = c a.x + s a.u
+    {
+        m.ax0 = fma(c, m.ax0, s * m.au0);
+        m.ax1 = fma(c, m.ax1, s * m.au1);
     }
     __device__ __forceinline__ double level_distributed(const Mine &m, int g, double c, double s) const
     {
@@ -760,7 +763,10 @@ struct CoopVmf {
     static constexpr int kVectors = KC;
     static constexpr bool kDistributed = false;
     struct Mine {};
-    __device__ __forceinline__ Mine mine(const typename Scalar::Coef &, int) const { return Mine{}; }
+    __device__ __forceinline__ Mine mine_init(int) const { return Mine{}; }
+    __device__ __forceinline__ void take_au(Mine &, int, int, double) const {}
+    __device__ __forceinline__ void take_ax(Mine &, int, int, double) const {}
+    __device__ __forceinline__ void advance(Mine &, double, double) const {}
     __device__ __forceinline__ double level_distributed(const Mine &, int, double, double) const { return 0.0; }
     Scalar sc;
     const double *rows;  // LDS [KC][DPAD]
@@ -794,7 +800,7 @@ struct CoopVmf {
 };
 
 template <class V, class TP, bool REPLAY>
-__global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, RunBlock a)
 {
     using Coef = typename TP::Scalar::Coef;
     constexpr int NV = TP::kVectors;
@@ -840,6 +846,7 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
     };
 
     Coef cf;
+    auto my = tp.mine_init(g);
     double lvl = 0.0;
     int64_t n_try = 0, steps_done = 0;
     int64_t until_keep = a.thin, row = 0;
@@ -876,13 +883,24 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
             for (int i = 0; i < V::N; ++i) u[i] *= rnw;
         }
         const bool refresh = (s % kCoefRefresh) == 0;
+        if constexpr (TP::kDistributed) {  // every lane keeps only the coefficients of its own segment
 #pragma unroll
-        for (int r = 0; r < NV; ++r) {
-            cf.au[r] = pdot(u, r);
-            if (refresh) cf.ax[r] = pdot(x, r);
+            for (int r = 0; r < NV; ++r) {
+                tp.take_au(my, g, r, pdot(u, r));
+                if (refresh) tp.take_ax(my, g, r, pdot(x, r));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                cf.au[r] = pdot(u, r);
+                if (refresh) cf.ax[r] = pdot(x, r);
+            }
         }
-        const auto my = tp.mine(cf, g);
-        const double lvl0 = TP::kDistributed ? tp.level_distributed(my, g, 1.0, 0.0) : tp.level0(cf, lvl, s == 0);
+        double lvl0;
+        if constexpr (TP::kDistributed)
+            lvl0 = tp.level_distributed(my, g, 1.0, 0.0);
+        else
+            lvl0 = tp.level0(cf, lvl, s == 0);
         double thr;
         bool finite;
         if (TP::kLinear) {
@@ -921,7 +939,10 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
                     const double theta = fma(hi - lo, uu, lo);
                     ++t;
                     fm::sincos_small(theta, sn, cs);
-                    lvl = TP::kDistributed ? tp.level_distributed(my, g, cs, sn) : tp.level(cf, cs, sn);
+                    if constexpr (TP::kDistributed)
+                        lvl = tp.level_distributed(my, g, cs, sn);
+                    else
+                        lvl = tp.level(cf, cs, sn);
                     accepted = lvl > thr;
                     if (!accepted && shrink) {
                         if (theta < 0.0)
@@ -937,8 +958,12 @@ __global__ void __launch_bounds__(kBlock) coopfast_kernel(TargetBlock tb, RunBlo
         if (accepted) {
 #pragma unroll
             for (int i = 0; i < V::N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
+            if constexpr (TP::kDistributed) {
+                tp.advance(my, cs, sn);
+            } else {
 #pragma unroll
-            for (int r = 0; r < NV; ++r) cf.ax[r] = fma(cs, cf.ax[r], sn * cf.au[r]);
+                for (int r = 0; r < NV; ++r) cf.ax[r] = fma(cs, cf.ax[r], sn * cf.au[r]);
+            }
             ++steps_done;
             if (a.samples != nullptr && --until_keep == 0) {
                 until_keep = a.thin;
