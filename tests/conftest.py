@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no binaries: build the HIP library (hipcc cross-compiles without a GPU) and
+    # the CPU oracle once, before collection imports anything that loads them
+    from geosss_amd import build as hip_build
+    if not os.path.exists(hip_build.LIB):
+        hip_build.build(verbose=False)
 
 
 def golden(name):
