@@ -140,3 +140,18 @@ def test_eight_million_chains_one_gpu(gs):
     ref = float(st["rej_per_step"].mean())
     assert abs(rej - ref) / ref < 0.03, (rej, ref)
     assert s.state_device.shape == (3, n)
+
+
+def test_ess_matches_reference_estimate(gs):
+    """ESS per step on the README target with the reference's IAT estimator: mean over 512 GPU chains vs
+    the reference chain of tests/golden/diagnostics_kat.npz (one chain: loose tolerance)."""
+    z, k = golden("traj_vmfmix_readme.npz"), golden("diagnostics_kat.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere_device(2, 512, seed=2).T
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=8)
+    s.advance(500)
+    X = s.sample(4001, as_tensor=True)
+    iat = gs.diagnostics.IAT(X.permute(0, 2, 1).contiguous())          # (chains, dims)
+    ours = 1.0 / iat.mean(0).cpu().numpy()
+    ref = 1.0 / k["vmf_IAT"]
+    assert np.all(ours / ref > 0.5) and np.all(ours / ref < 2.0), (ours, ref)
