@@ -155,3 +155,21 @@ def test_ess_matches_reference_estimate(gs):
     ours = 1.0 / iat.mean(0).cpu().numpy()
     ref = 1.0 / k["vmf_IAT"]
     assert np.all(ours / ref > 0.5) and np.all(ours / ref < 2.0), (ours, ref)
+
+
+def test_extreme_concentration_is_handled(gs, oracle):
+    """kappa = 2000 (> 714, where the reference's log(i0(kappa)) overflows and its sampler never returns):
+    both kernel families run without error flags, agree with each other, and the chains find the modes."""
+    modes = gs.sample_sphere(2, 3, seed=77)
+    pdf = gs.MixtureModel([gs.VonMisesFisher(2000.0 * m) for m in modes], [1.0, 2.0, 3.0])
+    x0 = gs.sample_sphere(2, 20_000, seed=78)
+    out = {}
+    for mode in ("fast", "exact"):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=5, mode=mode)
+        s.advance(300)
+        assert np.all(s.errors == 0)
+        out[mode] = s.state
+    assert np.max(np.abs(out["fast"] - out["exact"])) < 1e-9
+    cosang = np.max(out["fast"] @ modes.T, axis=1)
+    assert np.mean(cosang > 1 - 5 / 2000.0) > 0.95      # within a few 1/sqrt(kappa) of a mode
+    assert np.all(np.isfinite(pdf.log_prob(out["fast"][:100])))
