@@ -288,6 +288,7 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
         set_error("d must be >= 2 (got %d)", d);
         return GSSS_E_INVALID;
     }
+    if (select_vec(d, 0) < 0) return GSSS_E_UNSUPPORTED;  // before any parameter array is touched
     std::vector<double> blob;
     switch (desc->kind) {
     case GSSS_VMF_MIXTURE:
@@ -334,8 +335,6 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
         set_error("unknown target kind %d", desc->kind);
         return GSSS_E_INVALID;
     }
-    if (select_vec(d, 0) < 0) return GSSS_E_UNSUPPORTED;
-
     int ndev = gsss_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev) {
         set_error("device %d not available (%d HIP devices visible)", device, ndev);

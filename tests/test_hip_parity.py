@@ -374,3 +374,53 @@ def test_checkpoint_resume(gs, rng):
     b.advance(18)
     assert np.array_equal(b.state, ref.state)
     assert np.array_equal(b.n_reject_per_chain, ref.n_reject_per_chain) and b._step == 30
+
+
+def test_c_abi_argument_errors(gs):
+    """The C entry points refuse bad arguments with a negative code and a message (no exceptions cross
+    the ABI, nothing is launched)."""
+    import ctypes as C
+    import torch
+    from geosss_amd import _lib
+    lib = _lib.load()
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    h = pdf._device_target(0).handle
+    st = torch.zeros(3, 8, dtype=torch.float64, device="cuda")
+
+    def run(**kw):
+        a = _lib.RunArgs(state_dev=st.data_ptr(), n_chains=8, n_steps=1, thin=1, seed=1, sampler=0, mode=0,
+                         max_tries=10)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        rc = lib.gsss_run(h, C.byref(a), None)
+        return rc, lib.gsss_last_error().decode()
+
+    assert run()[0] == 0
+    for kw, code in ((dict(thin=0), -1), (dict(n_chains=-1), -1), (dict(max_tries=0), -1), (dict(sampler=5), -1),
+                     (dict(mode=7), -1), (dict(state_dev=None), -1), (dict(variant=99), -1),
+                     (dict(variant=7), -2),                               # lane10 does not cover d = 3
+                     (dict(chain_offset=2**48), -1),
+                     (dict(replay_dev=st.data_ptr(), replay_stride=0), -1),
+                     (dict(replay_dev=st.data_ptr(), replay_stride=4, rng_state_dev=st.data_ptr()), -1),
+                     (dict(rng_state_dev=st.data_ptr(), mode=1), -2)):
+        rc, msg = run(**kw)
+        assert rc == code and msg, (kw, rc, msg)
+    assert lib.gsss_run(None, None, None) == -1
+    assert run(n_chains=0)[0] == 0
+    # target descriptions
+    out = C.c_void_p()
+    mu = np.ones((2, 3))
+    bad = _lib.TargetDesc(1, 1, 2, 0, mu.ctypes.data, mu.ctypes.data, None, None, 0.0)   # d < 2
+    assert lib.gsss_target_create(C.byref(bad), 0, C.byref(out)) == -1 and not out.value
+    bad = _lib.TargetDesc(1, 3, 2, 0, None, None, None, None, 0.0)                        # missing arrays
+    assert lib.gsss_target_create(C.byref(bad), 0, C.byref(out)) == -1
+    bad = _lib.TargetDesc(9, 3, 2, 0, mu.ctypes.data, mu.ctypes.data, None, None, 0.0)   # unknown kind
+    assert lib.gsss_target_create(C.byref(bad), 0, C.byref(out)) == -1
+    ok = _lib.TargetDesc(1, 3, 2, 0, mu.ctypes.data, mu.ctypes.data, None, None, 0.0)
+    assert lib.gsss_target_create(C.byref(ok), 99, C.byref(out)) == -4                    # no such device
+    eye = np.eye(2000)
+    big = _lib.TargetDesc(2, 2000, 0, 0, None, None, eye.ctypes.data, None, 0.0)
+    assert lib.gsss_target_create(C.byref(big), 0, C.byref(out)) == -2                    # d beyond every layout
+    assert lib.gsss_target_dim(h) == 3 and lib.gsss_mode_supported(h, 1) == 1 and lib.gsss_mode_supported(h, 5) == 0
+    assert lib.gsss_variant_name(h, 0, 0) == b"lane3" and lib.gsss_variant_name(h, 1, 0) == b"fast-lane"
