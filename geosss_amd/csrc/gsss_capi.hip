@@ -426,6 +426,10 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("state_dev is null");
         return GSSS_E_INVALID;
     }
+    if (a->samples_chain_rows < 0 || (a->samples_chain_rows > 0 && a->samples_chain_rows < a->n_steps / a->thin)) {
+        set_error("samples_chain_rows must be 0 or >= the rows this call writes");
+        return GSSS_E_INVALID;
+    }
     if (a->replay_dev && a->replay_stride < 1) {
         set_error("replay_stride must be >= 1");
         return GSSS_E_INVALID;
@@ -449,6 +453,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     rb.step_offset = a->step_offset;
     rb.sampler = a->sampler;
     rb.max_tries = a->max_tries;
+    rb.keep_rows = a->samples_chain_rows;
     DeviceGuard guard(t->device);
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -40,7 +40,14 @@ struct RunBlock {
     int64_t n_chains, n_steps, thin;
     uint64_t seed, chain_offset, step_offset;
     int32_t sampler, max_tries;
+    int64_t keep_rows;  // > 0: samples are written chain-major [chain][keep_rows][d]; 0: [row][d][chain]
 };
+
+// address of component j of retained row `row` of chain c
+__device__ __forceinline__ size_t sample_index(const RunBlock &a, int64_t row, int j, int d, int64_t c)
+{
+    return a.keep_rows > 0 ? ((size_t)c * a.keep_rows + row) * d + j : ((size_t)row * d + j) * a.n_chains + c;
+}
 
 // ------------------------------------------------------------------------------------------
 // RNG stream (DESIGN.md "RNG stream"): Philox4x32-10, counter = (block, step_lo, chain_lo,
@@ -695,7 +702,7 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
 #pragma unroll
                 for (int i = 0; i < V::N; ++i) {
                     const int cc = V::comp(g, i);
-                    if (cc < d) a.samples[((size_t)row * d + cc) * n + c] = x[i];
+                    if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
                 }
             }
             ++row;

@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             ++cur.steps_done;
             if (a.samples != nullptr && cur.steps_done == (cur.row + 1) * thin) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) a.samples[((size_t)cur.row * D + j) * n + chain_id()] = cur.x[j];
+                for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
                 ++cur.row;
             }
             cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
 #pragma unroll
                     for (int i = 0; i < V::N; ++i) {
                         const int cc = V::comp(g, i);
-                        if (cc < d) a.samples[((size_t)row * d + cc) * n + c] = x[i];
+                        if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
                     }
                 }
                 ++row;

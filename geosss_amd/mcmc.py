@@ -257,10 +257,11 @@ class RejectionSphericalSliceSampler:
             self._sync_rng()
 
     # ------------------------------------------------------------------ running
-    def _launch(self, n_steps, samples=None, thin=1, replay=None):
+    def _launch(self, n_steps, samples=None, thin=1, replay=None, chain_rows=0, samples_ptr=None):
         a = _lib.RunArgs()
         a.state_dev = self._state.data_ptr()
-        a.samples_dev = samples.data_ptr() if samples is not None else None
+        a.samples_dev = samples_ptr if samples_ptr is not None else (samples.data_ptr() if samples is not None else None)
+        a.samples_chain_rows = int(chain_rows)
         a.n_reject_dev = self._n_reject.data_ptr()
         a.n_tries_dev = self._n_tries.data_ptr()
         a.err_dev = self._err.data_ptr()
@@ -284,11 +285,14 @@ class RejectionSphericalSliceSampler:
         _lib.check(self._lib.gsss_run(self._target_dev.handle, C.byref(a), self._stream()))
         self._step += int(n_steps)
 
-    def advance(self, n_steps, *, thin=None, out=None, replay=None):
+    def advance(self, n_steps, *, thin=None, out=None, replay=None, chain_major=False, row0=0):
         """Advance every chain by n_steps transitions on the GPU (asynchronously).
 
         thin=None keeps nothing; thin=t >= 1 keeps the state after every t-th step and returns a
-        CUDA tensor [n_steps // t, d, n_chains] (component-major, the kernels' native layout).
+        CUDA tensor [n_steps // t, d, n_chains] (component-major, the kernels' native layout), or --
+        with chain_major=True -- writes rows row0 .. row0 + n_steps//t - 1 of `out`, a contiguous
+        (n_chains, R, d) tensor in the reference's (chains, draws, dims) order (every chain appends to
+        its own contiguous run; no layout pass afterwards).
         `replay` (n_chains, stride) replays recorded draws instead of the Philox stream.
         """
         n_steps = int(n_steps)
@@ -311,21 +315,34 @@ class RejectionSphericalSliceSampler:
         if thin < 1:
             raise ValueError("thin must be >= 1")
         n_keep = n_steps // thin
-        if out is None:
-            out = torch.empty((n_keep, self.d, self.n_chains), dtype=torch.float64, device=self._tdev)
-        elif tuple(out.shape) != (n_keep, self.d, self.n_chains) or out.dtype != torch.float64 or not out.is_contiguous():
-            raise ValueError("out must be a contiguous float64 tensor [n_steps//thin, d, n_chains]")
+        if chain_major:
+            if (out is None or out.ndim != 3 or out.shape[0] != self.n_chains or out.shape[2] != self.d
+                    or out.dtype != torch.float64 or not out.is_contiguous() or row0 + n_keep > out.shape[1]):
+                raise ValueError("chain_major needs a contiguous float64 out of shape (n_chains, R, d) with room "
+                                 "for the rows written")
+            total = int(out.shape[1])
+
+            def ptr(r):
+                return out.data_ptr() + 8 * self.d * (row0 + r)
+        else:
+            if out is None:
+                out = torch.empty((n_keep, self.d, self.n_chains), dtype=torch.float64, device=self._tdev)
+            elif (tuple(out.shape) != (n_keep, self.d, self.n_chains) or out.dtype != torch.float64
+                  or not out.is_contiguous()):
+                raise ValueError("out must be a contiguous float64 tensor [n_steps//thin, d, n_chains]")
+            total = 0
+
+            def ptr(r):
+                return out.data_ptr() + 8 * self.d * self.n_chains * r
         if replay is not None:
-            self._launch(n_steps, samples=out, thin=thin, replay=replay)
+            self._launch(n_steps, thin=thin, replay=replay, chain_rows=total, samples_ptr=ptr(0))
             return out
         per = max(thin, (_MAX_STEPS_PER_LAUNCH // thin) * thin)
         done = 0
         while done < n_steps:
             m = min(per, n_steps - done)
-            rows = m // thin
-            if rows:
-                r0 = done // thin
-                self._launch(m, samples=out[r0:r0 + rows], thin=thin)
+            if m // thin:
+                self._launch(m, thin=thin, chain_rows=total, samples_ptr=ptr(done // thin))
             else:
                 self._launch(m)
             done += m
@@ -358,13 +375,11 @@ class RejectionSphericalSliceSampler:
         steps0 = self._step
         if skip:
             self.advance(skip)
-        rows = torch.empty((n_rows, self.d, self.n_chains), dtype=torch.float64, device=self._tdev)
-        rows[0].copy_(self._state)
-        if n_rows > 1:
-            self.advance((n_rows - 1) * thin, thin=thin, out=rows[1:])
+        # the kernels write straight into the reference's (chains, draws, dims) order
         out = torch.empty((self.n_chains, n_rows, self.d), dtype=torch.float64, device=self._tdev)
-        _lib.check(self._lib.gsss_samples_to_chains(rows.data_ptr(), out.data_ptr(), self.n_chains, n_rows, self.d,
-                                                    self.device, self._stream()))
+        out[:, 0, :] = self.state_rows()
+        if n_rows > 1:
+            self.advance((n_rows - 1) * thin, thin=thin, out=out, chain_major=True, row0=1)
         self._account_calls(self._step - steps0)
         self._check_errors()
         self._sync_rng()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 2
+#define GSSS_ABI_VERSION 3
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -98,7 +98,7 @@ typedef struct gsss_target_desc {
  */
 typedef struct gsss_run_args {
     double *state_dev;         /* [d][n_chains] in/out                                             */
-    double *samples_dev;       /* [n_steps/thin][d][n_chains] or NULL; state after every thin-th step */
+    double *samples_dev;       /* NULL or the state after every thin-th step, layout per samples_chain_rows    */
     int64_t *n_reject_dev;     /* [n_chains] or NULL; rejections are ADDED (RejectionSphericalSliceSampler.n_reject) */
     int64_t *n_tries_dev;      /* [n_chains] or NULL; log_prob(y) evaluations are ADDED            */
     int32_t *err_dev;          /* [n_chains] or NULL; GSSS_CHAIN_* bits are OR-ed in               */
@@ -118,6 +118,10 @@ typedef struct gsss_run_args {
                                   PCG64 words (state_hi, state_lo, inc_hi, inc_lo) of np.random.default_rng(seed).bit_generator,
                                   read at entry and written back at exit, so a chain consumes exactly the numbers the reference's
                                   sampler.rng would (mcmc.py:45, 387-395).  GSSS_MODE_EXACT only; `seed`/offsets are then unused */
+    int64_t samples_chain_rows; /* 0: samples_dev is [n_steps/thin][d][n_chains] (component-major, like state_dev).
+                                   R > 0: samples_dev points into a [n_chains][R][d] array -- the reference's (chains, draws,
+                                   dims) order -- and this call writes rows 0 .. n_steps/thin-1 of every chain's run of R rows
+                                   (offset the pointer by row0*d doubles to continue a run across calls) */
 } gsss_run_args;
 
 int gsss_abi_version(void);
