@@ -290,6 +290,7 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     }
     if (select_vec(d, 0) < 0) return GSSS_E_UNSUPPORTED;  // before any parameter array is touched
     std::vector<double> blob;
+    bool bingham_diagonal = false;
     switch (desc->kind) {
     case GSSS_VMF_MIXTURE:
         if (k < 1 || !desc->mu || !desc->logc) {
@@ -309,6 +310,16 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
             blob.insert(blob.end(), desc->mu, desc->mu + d);
         else
             blob.insert(blob.end(), (size_t)d, 0.0);
+        {
+            bool diag = true;
+            for (int i = 0; i < d && diag; ++i)
+                for (int j = 0; j < d; ++j)
+                    if (i != j && desc->A[(size_t)i * d + j] != 0.0) {
+                        diag = false;
+                        break;
+                    }
+            bingham_diagonal = diag;
+        }
         break;
     case GSSS_CURVE_VMF: {
         if (k < 2 || !desc->knots) {
@@ -360,7 +371,7 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     t->tb.blob = t->blob_dev;
     t->tb.kind = desc->kind;
     t->tb.d = d;
-    t->tb.k = k;
+    t->tb.k = desc->kind == GSSS_BINGHAM ? (bingham_diagonal ? 1 : 0) : k;  // Bingham: k flags a diagonal A
     t->tb.dpad = 0;
     t->tb.kappa = desc->kappa;
     *out = t;

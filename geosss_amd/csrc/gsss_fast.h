@@ -158,16 +158,36 @@ struct FastBingham {
     };
     static constexpr int kCoefWords = 5;
     __host__ __device__ static size_t lds_doubles() { return (size_t)D * D + D; }
+    bool diagonal;  // A is diagonal (the eigenbasis targets of scripts/bingham.py:131): O(d) coefficients
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         for (int i = threadIdx.x; i < D * D + D; i += kBlock) lds[i] = tb.blob[i];
         A = lds;
         b = lds + D * D;
+        diagonal = tb.k == 1;
     }
     __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D], double /*lvl*/,
                                            bool /*fresh*/) const
     {
         double qxx = 0.0, qxu = 0.0, quu = 0.0, bx = 0.0, bu = 0.0;
+        if (diagonal) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double ajj = A[j * D + j];
+                const double xa = x[j] * ajj, ua = u[j] * ajj;
+                qxx = fma(xa, x[j], qxx);
+                qxu = fma(xa, u[j], fma(ua, x[j], qxu));
+                quu = fma(ua, u[j], quu);
+                bx = fma(b[j], x[j], bx);
+                bu = fma(b[j], u[j], bu);
+            }
+            cf.qxx = qxx;
+            cf.qxu = qxu;
+            cf.quu = quu;
+            cf.bx = bx;
+            cf.bu = bu;
+            return qxx + bx;
+        }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             double xa = 0.0, ua = 0.0;  // (x A)_j, (u A)_j  (distributions.py:86 contracts rows first)
