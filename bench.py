@@ -31,7 +31,7 @@ FLOPS_SETUP = {"vmfmix_readme": 240.0, "vmfmix_k10_kappa500": 324.0, "bingham_d1
 FLOPS_TRY = {"vmfmix_readme": 152.0, "vmfmix_k10_kappa500": 411.0, "bingham_d10": 48.0}
 # HBM bytes per launch from the rocprofv3 PMC passes (profiles/), corrected as MI355X_MICROARCH.md prescribes;
 # filled in from the committed profile of the default workload
-TRAFFIC_BYTES_PER_LAUNCH = {"vmfmix_readme": 2 * 19716.6e3 + 62555.4e3}  # profiles/r01_*_summary.md: 2*FETCH_SIZE + WRITE_SIZE
+TRAFFIC_BYTES_PER_LAUNCH = {"vmfmix_readme": 2 * 19733.4e3 + 62701.2e3}  # profiles/r01_*_summary.md: 2*FETCH_SIZE + WRITE_SIZE
 
 README_MUS = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
 
