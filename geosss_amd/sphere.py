@@ -3,6 +3,8 @@
 The projections themselves run inside the HIP kernels; what is exposed here is the
 initial-state generator, the device twin of `sphere.sample_sphere`.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -10,7 +12,11 @@ from . import _lib
 
 
 def _device_index(device):
+    """None -> $GEOSSS_HIP_DEVICE if set, else torch's current device."""
     if device is None:
+        env = os.environ.get("GEOSSS_HIP_DEVICE")
+        if env is not None:
+            return int(env)
         return int(torch.cuda.current_device()) if torch.cuda.is_available() else 0
     if isinstance(device, torch.device):
         return 0 if device.index is None else int(device.index)
