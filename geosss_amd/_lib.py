@@ -10,7 +10,7 @@ VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
 SHRINK, REJECT = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GsssError(RuntimeError):
@@ -29,7 +29,8 @@ class RunArgs(C.Structure):
                 ("replay_stride", C.c_int64), ("n_chains", C.c_int64), ("n_steps", C.c_int64), ("thin", C.c_int64),
                 ("seed", C.c_uint64), ("chain_offset", C.c_uint64), ("step_offset", C.c_uint64),
                 ("sampler", C.c_int32), ("mode", C.c_int32), ("max_tries", C.c_int32), ("variant", C.c_int32),
-                ("rng_state_dev", C.c_void_p), ("samples_chain_rows", C.c_int64)]
+                ("rng_state_dev", C.c_void_p), ("samples_chain_rows", C.c_int64), ("placement", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 # symbol -> (restype, argtypes); must list every function include/gsss.h declares

@@ -465,6 +465,11 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     rb.sampler = a->sampler;
     rb.max_tries = a->max_tries;
     rb.keep_rows = a->samples_chain_rows;
+    if (a->placement < 0 || a->placement > 2) {
+        set_error("placement must be 0 (auto), 1 (packed) or 2 (spread)");
+        return GSSS_E_INVALID;
+    }
+    rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= 2048) ? 1 : 0;
     DeviceGuard guard(t->device);
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -41,6 +41,7 @@ struct RunBlock {
     uint64_t seed, chain_offset, step_offset;
     int32_t sampler, max_tries;
     int64_t keep_rows;  // > 0: samples are written chain-major [chain][keep_rows][d]; 0: [row][d][chain]
+    int32_t spread;     // lane layouts: one chain per WAVEFRONT (small ensembles: no divergence between chains)
 };
 
 // address of component j of retained row `row` of chain c
@@ -607,9 +608,13 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
     const int d = tb.d;
     const int g = threadIdx.x % V::L;
     const int64_t n = a.n_chains;
-    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / V::L) + threadIdx.x / V::L;
-    const bool active = c_raw < n;
-    const int64_t c = active ? c_raw : n - 1;  // tail lanes shadow the last chain and store nothing
+    // packed: consecutive lane groups take consecutive chains.  spread (lane layouts, small ensembles):
+    // one chain per wavefront -- lane 0 owns it, the other lanes shadow it, so the wave never diverges
+    const bool spread = V::L == 1 && a.spread;
+    const int64_t c_raw = spread ? (int64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64
+                                 : (int64_t)blockIdx.x * (kBlock / V::L) + threadIdx.x / V::L;
+    const bool active = c_raw < n && (!spread || threadIdx.x % 64 == 0);
+    const int64_t c = c_raw < n ? c_raw : n - 1;  // surplus lanes shadow a chain and store nothing
 
     double x[V::N];
 #pragma unroll

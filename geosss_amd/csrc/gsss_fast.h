@@ -385,13 +385,18 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     const int32_t max_tries = a.max_tries < (1 << 26) ? a.max_tries : (1 << 26) - 1;  // t shares a word with the flags
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
     constexpr bool kPark = fast_parks<D, TP>();
-    const int32_t base = (int32_t)blockIdx.x * fast_chains_per_block<D, TP>() + (int32_t)threadIdx.x;
+    // packed: lane l of block b owns chains b*P + l and (parking targets) b*P + 256 + l.
+    // spread (small ensembles): one chain per wavefront, owned by its lane 0; nothing is parked.
+    const bool spread = a.spread != 0;
+    const int32_t id0 = spread ? ((threadIdx.x % 64 == 0) ? (int32_t)blockIdx.x * (kBlock / 64) + (int32_t)threadIdx.x / 64 : n)
+                               : (int32_t)blockIdx.x * fast_chains_per_block<D, TP>() + (int32_t)threadIdx.x;
+    const int32_t id1 = spread ? n : id0 + kBlock;
 
     Chain cur;
-    int32_t slot = 0;               // which of the lane's two chains `cur` is: id = base + slot * kBlock
+    int32_t slot = 0;               // which of the lane's two chains `cur` is
     int32_t parked_status = kDone;  // status of the chain in LDS
 
-    auto chain_id = [&]() { return base + slot * kBlock; };
+    auto chain_id = [&]() { return slot ? id1 : id0; };
     auto philox = [&]() {
         PhiloxDraws<V> dr;
         dr.init(a, chain_id(), D);
@@ -650,7 +655,7 @@ int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
             return GSSS_E_HIP;
         }
     }
-    constexpr int per_block = fast_chains_per_block<D, TP>();
+    const int per_block = rb.spread ? kBlock / 64 : fast_chains_per_block<D, TP>();
     const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
     hipError_t e = hipGetLastError();

@@ -77,7 +77,7 @@ int do_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     if (lds > 48 * 1024)
         GSSS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t per_block = kBlock / V::L;
+    const int64_t per_block = (V::L == 1 && rb.spread) ? kBlock / 64 : kBlock / V::L;
     const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
     GSSS_HIP_TRY(hipGetLastError());

@@ -75,13 +75,16 @@ class RejectionSphericalSliceSampler:
     _sampler = _lib.REJECT
 
     def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="auto", max_tries=None,
-                 chain_offset=0, step_offset=0, variant=0, rng="philox"):
+                 chain_offset=0, step_offset=0, variant=0, rng="philox", placement="auto"):
         _lib.require_device()
         self._lib = _lib.load()
         self.target = distribution
         if rng not in ("philox", "numpy"):
             raise ValueError("rng must be 'philox' or 'numpy'")
         self.rng_kind = rng
+        if placement not in ("auto", "packed", "spread"):
+            raise ValueError("placement must be 'auto', 'packed' or 'spread'")
+        self._placement = {"auto": 0, "packed": 1, "spread": 2}[placement]
         self._seed_arg = seed
         many_seeds = isinstance(seed, (list, tuple))
         self.rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(
@@ -262,6 +265,7 @@ class RejectionSphericalSliceSampler:
         a.state_dev = self._state.data_ptr()
         a.samples_dev = samples_ptr if samples_ptr is not None else (samples.data_ptr() if samples is not None else None)
         a.samples_chain_rows = int(chain_rows)
+        a.placement = self._placement
         a.n_reject_dev = self._n_reject.data_ptr()
         a.n_tries_dev = self._n_tries.data_ptr()
         a.err_dev = self._err.data_ptr()

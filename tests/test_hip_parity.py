@@ -424,3 +424,20 @@ def test_c_abi_argument_errors(gs):
     assert lib.gsss_target_create(C.byref(big), 0, C.byref(out)) == -2                    # d beyond every layout
     assert lib.gsss_target_dim(h) == 3 and lib.gsss_mode_supported(h, 1) == 1 and lib.gsss_mode_supported(h, 5) == 0
     assert lib.gsss_variant_name(h, 0, 0) == b"lane3" and lib.gsss_variant_name(h, 1, 0) == b"fast-lane"
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_placement_does_not_change_results(gs, mode):
+    """Spread (one chain per wavefront, the default for small ensembles) and packed placements of the
+    lane-per-chain kernels give bit-identical chains."""
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere(2, 37, seed=6)
+    out = {}
+    for pl in ("packed", "spread", "auto"):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, 17, mode=mode, placement=pl)
+        out[pl] = (s.sample(40, thin=2), s.n_reject_per_chain)
+    for pl in ("spread", "auto"):
+        assert np.array_equal(out[pl][0], out["packed"][0]) and np.array_equal(out[pl][1], out["packed"][1])
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, placement="sideways")
