@@ -667,9 +667,16 @@ int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 }
 
 template <int D, class TP>
+int do_wave(const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
+
+template <int D, class TP>
 int do_fast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
 {
-    return replay ? do_fast_run<D, TP, true>(tb, rb, st) : do_fast_run<D, TP, false>(tb, rb, st);
+    if (replay) return do_fast_run<D, TP, true>(tb, rb, st);
+    if constexpr (D <= 16) {
+        if (rb.spread) return do_wave<D, TP>(tb, rb, st);  // small ensemble: one wavefront per chain
+    }
+    return do_fast_run<D, TP, false>(tb, rb, st);
 }
 
 // per-target entry points (one translation unit each); GSSS_E_UNSUPPORTED when no instantiation
@@ -1037,6 +1044,221 @@ int do_coopfast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStrea
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("cooperative fast kernel launch failed: %s", hipGetErrorString(e));
+        return GSSS_E_HIP;
+    }
+    return GSSS_OK;
+}
+
+}  // namespace gsss
+
+// ==========================================================================================
+// One wavefront per chain, speculative tries: the latency path for small ensembles.
+//
+// In a spread launch a chain has a whole wavefront to itself and is bound by the LATENCY of its
+// sequential shrink loop.  But the bracket sequence of a step does not depend on any log-density:
+// while tries are rejected, theta_t and the shrunken bracket follow from the uniforms alone
+// (mcmc.py:395, 400: the side that shrinks is the sign of theta).  So the wave draws the uniforms of
+// 16 tries at once (one Philox block per lane), replays the bracket recurrence, lets lane t evaluate
+// try t, and a ballot finds the first accepted one -- the same try the sequential loop would stop at,
+// hence the same chain bit for bit.  Branch-light: no data-dependent loop unless all 16 are rejected.
+// ==========================================================================================
+namespace gsss {
+
+constexpr int kSpecTries = 16;
+
+__device__ __forceinline__ double lane_broadcast_dyn(double v, int lane)  // `lane` wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int D, class TP>
+__global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a)
+{
+    using V = LaneVec<D>;
+    using Coef = typename TP::Coef;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    TP tp;
+    tp.stage(lds, tb);
+    __syncthreads();
+
+    const int lane = threadIdx.x % 64;
+    const int64_t n = a.n_chains;
+    const int64_t c = (int64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    if (c >= n) return;  // whole wavefront
+    const bool shrink = a.sampler == GSSS_SHRINK;
+    constexpr uint32_t kNormalBlocks = (uint32_t)((D + 3) / 4);
+    constexpr uint32_t kTryBase = 1u + kNormalBlocks;
+    constexpr int kPairs = (D + 1) / 2;
+
+    double x[D];  // wave-uniform values: every lane holds the chain's state
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = a.state[(size_t)j * n + c];
+    PhiloxDraws<V> dr;
+    dr.init(a, c, D);
+
+    Coef cf;
+    double lvl = 0.0;
+    int64_t n_try = 0, steps_done = 0, until_keep = a.thin, row = 0;
+    int err = 0;
+
+    for (int64_t s = 0; s < a.n_steps; ++s) {
+        dr.begin_step(a.step_offset + (uint64_t)s);
+        // ---- every RNG block of the step in one go: lanes 0-7 the tries' blocks, lane 8 block 0, lanes 9.. the normals'
+        uint32_t w[4];
+        {
+            const uint32_t blk = lane < 8 ? kTryBase + (uint32_t)lane : (lane == 8 ? 0u : (uint32_t)(lane - 8));
+            dr.words(blk, w);
+        }
+        const double pair_u0 = u53(w[0], w[1]), pair_u1 = u53(w[2], w[3]);  // lanes 0-7: tries 2l, 2l+1; lane 8: U_thr, U_theta0
+        const double u_thr = lane_broadcast(pair_u0, 8), u_th0 = lane_broadcast(pair_u1, 8);
+        // ---- normals: Box-Muller pair p on lane p (words of block 1 + p/2, held by lane 9 + p/2)
+        double u[D];
+        {
+            double z0 = 0.0, z1 = 0.0;
+            uint32_t wr = 0u, wa = 0u;
+#pragma unroll
+            for (int p = 0; p < kPairs; ++p) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)w[2 * (p & 1)], 9 + p / 2);
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)w[2 * (p & 1) + 1], 9 + p / 2);
+                if (lane == p) {
+                    wr = r;
+                    wa = g;
+                }
+            }
+            box_muller32(wr, wa, z0, z1);
+#pragma unroll
+            for (int p = 0; p < kPairs; ++p) {
+                u[2 * p] = lane_broadcast(z0, p);
+                if (2 * p + 1 < D) u[2 * p + 1] = lane_broadcast(z1, p);
+            }
+        }
+        {   // u = spherical_projection(z, x)
+            const double rnx = inv_norm(vdot<V>(x, x));
+            double cz = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) cz = fma(u[j], x[j] * rnx, cz);
+#pragma unroll
+            for (int j = 0; j < D; ++j) u[j] = fma(-cz, x[j] * rnx, u[j]);
+            const double rnw = inv_norm(vdot<V>(u, u));
+#pragma unroll
+            for (int j = 0; j < D; ++j) u[j] *= rnw;
+        }
+        const double lvl0 = tp.make(cf, x, u, lvl, s == 0);
+        double thr;
+        bool finite;
+        if (TP::kLinear) {
+            thr = lvl0 * u_thr;
+            finite = lvl0 > 0.0 && lvl0 < INFINITY;
+        } else {
+            thr = lvl0 + fm::log_fast(u_thr);
+            finite = lvl0 > -INFINITY && lvl0 < INFINITY;
+        }
+        if (!finite) {
+            err |= GSSS_CHAIN_NONFINITE;
+            break;
+        }
+        double lo, hi;
+        if (shrink) {
+            hi = kTwoPi * u_th0;
+            lo = hi - kTwoPi;
+        } else {
+            lo = 0.0;
+            hi = kTwoPi;
+        }
+        // ---- batches of 16 speculative tries
+        int t_base = 0;
+        bool accepted = false;
+        for (;;) {
+            if (t_base >= a.max_tries) {
+                err |= GSSS_CHAIN_MAX_TRIES;
+                break;
+            }
+            double tu0 = pair_u0, tu1 = pair_u1;
+            if (t_base > 0) {  // rare: a further batch needs its own blocks
+                uint32_t w2[4];
+                dr.words(kTryBase + (uint32_t)(t_base >> 1) + (uint32_t)(lane & 7), w2);
+                tu0 = u53(w2[0], w2[1]);
+                tu1 = u53(w2[2], w2[3]);
+            }
+            // bracket recurrence, identical on every lane; lane t keeps theta_t
+            double my_theta = 0.0;
+#pragma unroll
+            for (int t = 0; t < kSpecTries; ++t) {
+                const double ut = lane_broadcast((t & 1) ? tu1 : tu0, t >> 1);
+                const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
+                if (lane == t) my_theta = theta;
+                if (shrink) {                               // mcmc.py:400, assuming try t is rejected
+                    if (theta < 0.0)
+                        lo = theta;
+                    else
+                        hi = theta;
+                }
+            }
+            double sn, cs;
+            fm::sincos_small(my_theta, sn, cs);
+            const double my_lvl = tp.level(cf, cs, sn, thr);
+            const bool ok = lane < kSpecTries && t_base + lane < a.max_tries && my_lvl > thr;  // mcmc.py:397
+            const unsigned long long mask = __ballot(ok);
+            if (mask != 0ull) {
+                const int T = (int)__builtin_ctzll(mask);  // the first accepted try: where the sequential loop stops
+                const double acs = lane_broadcast_dyn(cs, T), asn = lane_broadcast_dyn(sn, T);
+                lvl = lane_broadcast_dyn(my_lvl, T);
+#pragma unroll
+                for (int j = 0; j < D; ++j) x[j] = fma(asn, u[j], acs * x[j]);  // mcmc.py:396
+                n_try += t_base + T + 1;
+                accepted = true;
+                break;
+            }
+            const int left = a.max_tries - t_base;
+            if (left <= kSpecTries) {
+                n_try += a.max_tries;
+                err |= GSSS_CHAIN_MAX_TRIES;
+                break;
+            }
+            t_base += kSpecTries;
+        }
+        if (!accepted) break;
+        ++steps_done;
+        if (a.samples != nullptr && --until_keep == 0) {
+            until_keep = a.thin;
+            if (lane < D) {
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (lane == j) a.samples[sample_index(a, row, j, D, c)] = x[j];
+            }
+            ++row;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) a.state[(size_t)j * n + c] = x[j];
+        if (a.n_reject) a.n_reject[c] += n_try - steps_done;
+        if (a.n_tries) a.n_tries[c] += n_try;
+        if (a.err && err) a.err[c] |= err;
+    }
+}
+
+template <int D, class TP>
+int do_wave(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
+{
+    static_assert((D + 1) / 2 <= 8 && (D + 3) / 4 <= 55, "Box-Muller pairs must fit the lanes reserved for them");
+    const size_t lds = TP::lds_doubles() * sizeof(double);
+    auto kern = wave_kernel<D, TP>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GSSS_E_HIP;
+        }
+    }
+    const int64_t grid = (rb.n_chains + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("wave kernel launch failed: %s", hipGetErrorString(e));
         return GSSS_E_HIP;
     }
     return GSSS_OK;

@@ -115,12 +115,15 @@ def test_philox_stream_matches_oracle(gs, oracle, name, n_chains, n_steps, sampl
     kind = oracle.REJECT if sampler == "reject" else oracle.SHRINK
     want = oracle.run(tgt, x0, n_steps, seed=2024, chain_offset=1000, step_offset=7, sampler=kind, n_threads=8)
     cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
-    s = cls(pdf, x0, seed=2024, chain_offset=1000, step_offset=7, mode=mode)
-    kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()  # (chains, steps, d)
-    assert np.all(s.errors == 0) and np.all(want["err"] == 0)
-    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
-    assert np.array_equal(s.n_reject_per_chain, want["n_reject"])
-    assert np.max(np.abs(kept - want["samples"])) < TOL
+    # both placements: packed = lane-per-chain kernels, spread = one wavefront per chain (in fast mode the
+    # speculative wave kernel)
+    for placement in ("packed", "spread"):
+        s = cls(pdf, x0, seed=2024, chain_offset=1000, step_offset=7, mode=mode, placement=placement)
+        kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()  # (chains, steps, d)
+        assert np.all(s.errors == 0) and np.all(want["err"] == 0)
+        assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+        assert np.array_equal(s.n_reject_per_chain, want["n_reject"])
+        assert np.max(np.abs(kept - want["samples"])) < TOL
 
 
 def test_sample_sphere_matches_oracle(gs, oracle):
