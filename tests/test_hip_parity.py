@@ -444,3 +444,18 @@ def test_placement_does_not_change_results(gs, mode):
         assert np.array_equal(out[pl][0], out["packed"][0]) and np.array_equal(out[pl][1], out["packed"][1])
     with pytest.raises(ValueError):
         gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, placement="sideways")
+
+
+def test_long_chains_stay_on_the_oracle_trajectory(gs, oracle):
+    """20 000 steps: rounding differences between device and host arithmetic do not accumulate beyond
+    1e-10, no accept decision flips (tries equal exactly), in either kernel family."""
+    z = golden("traj_vmfmix_readme.npz")
+    pdf, tgt = product_target(z), oracle.Target.from_fixture(z)
+    x0 = oracle.sample_sphere(4, 48, 3)
+    n_steps = 20_000
+    want = oracle.run(tgt, x0, n_steps, seed=31, keep_samples=False, n_threads=8)
+    for mode, placement in (("fast", "spread"), ("fast", "packed"), ("exact", "packed")):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=31, mode=mode, placement=placement)
+        s.advance(n_steps)
+        assert np.array_equal(s.n_tries_per_chain, want["n_tries"]), (mode, placement)
+        assert np.max(np.abs(s.state - want["state"])) < TOL, (mode, placement)
