@@ -478,11 +478,13 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("replay_dev and rng_state_dev are mutually exclusive");
         return GSSS_E_INVALID;
     }
-    if (a->rng_state_dev && a->mode == GSSS_MODE_FAST) {
-        set_error("the numpy stream is served by the exact kernels only (mode = GSSS_MODE_EXACT)");
+
+    const int draws = replay ? kDrawsReplay : (a->rng_state_dev ? kDrawsNumpy : kDrawsPhilox);
+    if (a->mode == GSSS_MODE_FAST && a->rng_state_dev && !(rb.spread && t->tb.d <= 16)) {
+        set_error("in fast mode the numpy stream is served by the one-wavefront-per-chain kernel only "
+                  "(spread placement, d <= 16); use GSSS_MODE_EXACT");
         return GSSS_E_UNSUPPORTED;
     }
-    const int draws = replay ? kDrawsReplay : (a->rng_state_dev ? kDrawsNumpy : kDrawsPhilox);
     if (a->mode == GSSS_MODE_FAST) {
         if (a->n_steps > 0x7FFFFFFFll || a->thin > 0x7FFFFFFFll || a->n_chains > 0x7FFFFFFFll - 1024 ||
             a->replay_stride > 0x7FFFFFFFll) {

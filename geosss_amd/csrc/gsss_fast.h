@@ -1073,7 +1073,10 @@ __device__ __forceinline__ double lane_broadcast_dyn(double v, int lane)  // `la
     return __hiloint2double(hi, lo);
 }
 
-template <int D, class TP>
+// NUMPY = true: the draws come from numpy's own PCG64 / ziggurat stream (sequential by nature: every lane
+// runs the identical generator; lane t snapshots the generator after try t's uniform, and the accepted
+// try's snapshot becomes the stream position, so exactly the reference's numbers are consumed).
+template <int D, class TP, bool NUMPY>
 __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
@@ -1081,6 +1084,8 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
+    NumpyDraws<V> nd;
+    if (NUMPY) nd.stage(lds + TP::lds_doubles());
     __syncthreads();
 
     const int lane = threadIdx.x % 64;
@@ -1096,7 +1101,10 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
 #pragma unroll
     for (int j = 0; j < D; ++j) x[j] = a.state[(size_t)j * n + c];
     PhiloxDraws<V> dr;
-    dr.init(a, c, D);
+    if (NUMPY)
+        nd.init(a, c, D);
+    else
+        dr.init(a, c, D);
 
     Coef cf;
     double lvl = 0.0;
@@ -1104,6 +1112,12 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
     int err = 0;
 
     for (int64_t s = 0; s < a.n_steps; ++s) {
+        double u[D], u_thr, u_th0, pair_u0 = 0.0, pair_u1 = 0.0;
+        if (NUMPY) {
+            nd.normals(u, 0);                            // mcmc.py:387
+            u_thr = nd.next_double();                    // mcmc.py:389
+            u_th0 = shrink ? nd.next_double() : 0.0;     // mcmc.py:391
+        } else {
         dr.begin_step(a.step_offset + (uint64_t)s);
         // ---- every RNG block of the step in one go: lanes 0-7 the tries' blocks, lane 8 block 0, lanes 9.. the normals'
         uint32_t w[4];
@@ -1111,10 +1125,11 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
             const uint32_t blk = lane < 8 ? kTryBase + (uint32_t)lane : (lane == 8 ? 0u : (uint32_t)(lane - 8));
             dr.words(blk, w);
         }
-        const double pair_u0 = u53(w[0], w[1]), pair_u1 = u53(w[2], w[3]);  // lanes 0-7: tries 2l, 2l+1; lane 8: U_thr, U_theta0
-        const double u_thr = lane_broadcast(pair_u0, 8), u_th0 = lane_broadcast(pair_u1, 8);
+        pair_u0 = u53(w[0], w[1]);  // lanes 0-7: tries 2l, 2l+1; lane 8: U_thr, U_theta0
+        pair_u1 = u53(w[2], w[3]);
+        u_thr = lane_broadcast(pair_u0, 8);
+        u_th0 = lane_broadcast(pair_u1, 8);
         // ---- normals: Box-Muller pair p on lane p (words of block 1 + p/2, held by lane 9 + p/2)
-        double u[D];
         {
             double z0 = 0.0, z1 = 0.0;
             uint32_t wr = 0u, wa = 0u;
@@ -1133,6 +1148,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                 u[2 * p] = lane_broadcast(z0, p);
                 if (2 * p + 1 < D) u[2 * p + 1] = lane_broadcast(z1, p);
             }
+        }
         }
         {   // u = spherical_projection(z, x)
             const double rnx = inv_norm(vdot<V>(x, x));
@@ -1176,7 +1192,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                 break;
             }
             double tu0 = pair_u0, tu1 = pair_u1;
-            if (t_base > 0) {  // rare: a further batch needs its own blocks
+            if (!NUMPY && t_base > 0) {  // rare: a further batch needs its own blocks
                 uint32_t w2[4];
                 dr.words(kTryBase + (uint32_t)(t_base >> 1) + (uint32_t)(lane & 7), w2);
                 tu0 = u53(w2[0], w2[1]);
@@ -1184,9 +1200,19 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
             }
             // bracket recurrence, identical on every lane; lane t keeps theta_t
             double my_theta = 0.0;
+            uint64_t my_sh = 0, my_sl = 0;  // numpy stream: generator state right after try t's uniform
 #pragma unroll
             for (int t = 0; t < kSpecTries; ++t) {
-                const double ut = lane_broadcast((t & 1) ? tu1 : tu0, t >> 1);
+                double ut;
+                if (NUMPY) {
+                    ut = nd.next_double();
+                    if (lane == t) {
+                        my_sh = nd.sh;
+                        my_sl = nd.sl;
+                    }
+                } else {
+                    ut = lane_broadcast((t & 1) ? tu1 : tu0, t >> 1);
+                }
                 const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
                 if (lane == t) my_theta = theta;
                 if (shrink) {                               // mcmc.py:400, assuming try t is rejected
@@ -1205,6 +1231,12 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                 const int T = (int)__builtin_ctzll(mask);  // the first accepted try: where the sequential loop stops
                 const double acs = lane_broadcast_dyn(cs, T), asn = lane_broadcast_dyn(sn, T);
                 lvl = lane_broadcast_dyn(my_lvl, T);
+                if (NUMPY) {  // the stream stands right after the accepted try's uniform
+                    nd.sh = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_sh >> 32), T) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_sh, T);
+                    nd.sl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_sl >> 32), T) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_sl, T);
+                }
 #pragma unroll
                 for (int j = 0; j < D; ++j) x[j] = fma(asn, u[j], acs * x[j]);  // mcmc.py:396
                 n_try += t_base + T + 1;
@@ -1238,14 +1270,16 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
         if (a.n_tries) a.n_tries[c] += n_try;
         if (a.err && err) a.err[c] |= err;
     }
+    if (NUMPY) nd.finish(a, c, lane == 0);
 }
 
 template <int D, class TP>
 int do_wave(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
     static_assert((D + 1) / 2 <= 8 && (D + 3) / 4 <= 55, "Box-Muller pairs must fit the lanes reserved for them");
-    const size_t lds = TP::lds_doubles() * sizeof(double);
-    auto kern = wave_kernel<D, TP>;
+    const bool numpy = rb.rng_state != nullptr;
+    const size_t lds = (TP::lds_doubles() + (numpy ? NumpyDraws<LaneVec<D>>::kLdsDoubles : 0)) * sizeof(double);
+    auto kern = numpy ? wave_kernel<D, TP, true> : wave_kernel<D, TP, false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -100,14 +100,21 @@ class RejectionSphericalSliceSampler:
         self.variant = int(variant)
         self._step = int(step_offset)
         self._target_dev = distribution._device_target(self.device)
+        self._set_state(initial_state)
         if rng == "numpy":
+            # sequential per chain: fast mode serves it with the one-wavefront-per-chain kernel only
+            wave_ok = (self._placement != 1 and self.n_chains <= 2048 and distribution.d <= 16 and not variant and
+                       self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST))
+            if mode == "fast" and not wave_ok:
+                raise ValueError("rng='numpy' in fast mode needs a small ensemble (<= 2048 chains, spread placement) "
+                                 "of a shape the fast kernels are built for; use mode='exact' or 'auto'")
+            if mode == "auto":
+                mode = self.mode = "fast" if wave_ok else "exact"
             if mode == "fast":
-                raise ValueError("the numpy stream is served by the exact kernels (mode='exact' or 'auto')")
-            mode = self.mode = "exact"
+                self._placement = 2
         if mode == "auto":  # the throughput kernels where they are built for this shape, else the generic ones
             fast_ok = self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST) and not variant
             self.mode = "fast" if fast_ok else "exact"
-        self._set_state(initial_state)
         n = self.n_chains
         self._n_reject = torch.zeros(n, dtype=torch.int64, device=self._tdev)
         self._n_tries = torch.zeros(n, dtype=torch.int64, device=self._tdev)

@@ -296,6 +296,7 @@ def test_readme_call_from_seed(gs):
     pdf = product_target(t)
     type(pdf).log_prob.reset_counters()
     s = gs.ShrinkageSphericalSliceSampler(pdf, np.array([-0.86, 0.19, -0.47]), 3521, rng="numpy")
+    assert s.mode == "fast"                      # one wavefront per chain, 16 speculative tries per step
     out = s.sample(1000, 100)
     assert out.shape == (1000, 3)
     assert np.max(np.abs(out - z["samples"])) < TOL
@@ -310,17 +311,31 @@ def test_readme_call_from_seed(gs):
 
 
 @pytest.mark.parametrize("name", trajectory_names("shrink") + trajectory_names("reject"))
-def test_reference_chain_from_seed(gs, name):
-    """Every golden reference chain reproduced on the GPU from (pdf, x0, seed) alone."""
+@pytest.mark.parametrize("mode", ["exact", "auto"])
+def test_reference_chain_from_seed(gs, name, mode):
+    """Every golden reference chain reproduced on the GPU from (pdf, x0, seed) alone, by the exact kernels
+    and (mode auto: where built) by the speculative one-wavefront-per-chain kernel."""
     z = golden(name + ".npz")
     pdf = product_target(z)
     cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
-    s = cls(pdf, z["x0"], int(z["seed"]), rng="numpy")
+    s = cls(pdf, z["x0"], int(z["seed"]), rng="numpy", mode=mode)
+    if mode == "auto" and s.mode == "exact":
+        pytest.skip("no fast kernel for this shape: covered by the exact run")
     n = len(z["states"]) - 1
     out = s.sample(n + 1)
     assert np.array_equal(out[0], z["x0"])
     assert np.max(np.abs(out - z["states"])) < TOL
     assert s.n_reject == int(z["n_reject"])
+    # the generator the caller sees has moved exactly as the reference's would have
+    ref = np.random.default_rng(int(z["seed"]))
+    consumed = len(z["draws"])
+    d = len(z["x0"])
+    for i in range(n):  # replay the reference's consumption pattern on a plain numpy generator
+        ref.standard_normal(d)
+        for _ in range(int(z["step_draw_offset"][i + 1] - z["step_draw_offset"][i]) - d):
+            ref.random()
+    assert consumed == int(z["step_draw_offset"][-1])
+    assert s.rng.bit_generator.state["state"] == ref.bit_generator.state["state"]
 
 
 def test_numpy_stream_many_chains(gs, oracle):
@@ -335,7 +350,7 @@ def test_numpy_stream_many_chains(gs, oracle):
     got = s.advance(15, thin=1).permute(2, 0, 1).cpu().numpy()
     assert np.max(np.abs(got - want["samples"])) < TOL
     assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):  # d = 50: no one-wavefront kernel, fast mode cannot serve numpy's stream
         gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, rng="numpy", mode="fast")
 
 
@@ -390,6 +405,7 @@ def test_c_abi_argument_errors(gs):
     pdf = product_target(z)
     h = pdf._device_target(0).handle
     st = torch.zeros(3, 8, dtype=torch.float64, device="cuda")
+    words = torch.ones(8, 4, dtype=torch.int64, device="cuda")   # stands in for 8 PCG64 states
 
     def run(**kw):
         a = _lib.RunArgs(state_dev=st.data_ptr(), n_chains=8, n_steps=1, thin=1, seed=1, sampler=0, mode=0,
@@ -405,8 +421,9 @@ def test_c_abi_argument_errors(gs):
                      (dict(variant=7), -2),                               # lane10 does not cover d = 3
                      (dict(chain_offset=2**48), -1),
                      (dict(replay_dev=st.data_ptr(), replay_stride=0), -1),
-                     (dict(replay_dev=st.data_ptr(), replay_stride=4, rng_state_dev=st.data_ptr()), -1),
-                     (dict(rng_state_dev=st.data_ptr(), mode=1), -2)):
+                     (dict(replay_dev=st.data_ptr(), replay_stride=4, rng_state_dev=words.data_ptr()), -1),
+                     (dict(rng_state_dev=words.data_ptr(), mode=1, placement=1), -2),   # numpy stream + packed fast kernel
+                     (dict(placement=3), -1), (dict(samples_chain_rows=-1), -1)):
         rc, msg = run(**kw)
         assert rc == code and msg, (kw, rc, msg)
     assert lib.gsss_run(None, None, None) == -1
