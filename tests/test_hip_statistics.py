@@ -173,3 +173,18 @@ def test_extreme_concentration_is_handled(gs, oracle):
     cosang = np.max(out["fast"] @ modes.T, axis=1)
     assert np.mean(cosang > 1 - 5 / 2000.0) > 0.95      # within a few 1/sqrt(kappa) of a mode
     assert np.all(np.isfinite(pdf.log_prob(out["fast"][:100])))
+
+
+def test_bingham_mixing_matches_reference(gs):
+    """Bingham d=10 (scripts/bingham.py): IAT per coordinate and the hopping frequency between the two
+    antipodal modes, 512 GPU chains against the reference chain of diagnostics_kat.npz."""
+    z, k = golden("traj_bingham_d10_vmax30.npz"), golden("diagnostics_kat.npz")
+    pdf = product_target(z)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.repeat(z["x0"][None], 512, axis=0), seed=12)
+    s.advance(500)
+    X = s.sample(3000, as_tensor=True)                                   # (chains, draws, dims)
+    iat = gs.diagnostics.IAT(X.permute(0, 2, 1).contiguous()).mean(0).cpu().numpy()
+    ratio = iat / k["bingham_IAT"]
+    assert np.all(ratio > 0.4) and np.all(ratio < 2.5), ratio
+    hop = float(gs.diagnostics.hopping_frequency(X, k["bingham_mode"]).mean())
+    assert abs(hop - float(k["bingham_hop"])) < 0.35 * float(k["bingham_hop"]) + 0.002, (hop, float(k["bingham_hop"]))
