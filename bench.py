@@ -45,6 +45,10 @@ def make_target(gs, name):
         return gs.MixtureModel([gs.VonMisesFisher(500.0 * m) for m in modes]), 3
     if name == "bingham_d10":
         return gs.random_bingham(d=10, vmax=30.0, vmin=0.0, eigensystem=True, seed=6982), 10
+    if name == "bingham_d50":  # scripts/bingham.py ind=1
+        return gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=True, seed=6982), 50
+    if name == "bingham_d50_dense":
+        return gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=False, seed=6982), 50
     if name.startswith("curve_d"):
         d = int(name[len("curve_d"):])
         return gs.CurvedVonMisesFisher(gs.SlerpCurve(gs.brownian_curve(10, d, 0.5, seed=4562)), 800.0), d

@@ -698,11 +698,23 @@ namespace gsss {
 
 constexpr int kCoefRefresh = 64;  // recompute a_i.x from x every this many steps (bounds rounding drift)
 
+// LDS doubles of a cooperative target's parameters (Bingham's depend on d)
+template <class TP>
+__host__ __device__ inline size_t coop_param_doubles(int d)
+{
+    if constexpr (TP::kQuadratic)
+        return TP::lds_doubles(d);
+    else
+        return TP::lds_doubles();
+}
+
 template <class V, int NK>
 struct CoopCurve {
     using Scalar = FastCurve<1, NK>;  // only its level() and Coef are used
     static constexpr bool kLinear = false;
     static constexpr int kVectors = NK;
+    static constexpr bool kQuadratic = false;
+    static constexpr int kScratchPerGroup = 0;
     Scalar sc;
     const double *rows;  // LDS [NK][DPAD]
     __host__ __device__ static size_t lds_doubles() { return (size_t)NK * V::DPAD + 4 * (size_t)(NK - 1); }
@@ -793,6 +805,8 @@ struct CoopVmf {
     using Scalar = FastVmf<1, KC>;
     static constexpr bool kLinear = true;
     static constexpr int kVectors = KC;
+    static constexpr bool kQuadratic = false;
+    static constexpr int kScratchPerGroup = 0;
     static constexpr bool kDistributed = false;
     struct Mine {};
     __device__ __forceinline__ Mine mine_init(int) const { return Mine{}; }
@@ -831,6 +845,102 @@ struct CoopVmf {
     }
 };
 
+// Bingham / BinghamFisher for large d: the five coefficients of q(theta) (FastBingham::Coef) are group
+// sums; a general A needs (xA)_j and (uA)_j for the lane's own columns j, i.e. all of x and u, which the
+// group publishes in an LDS row first; a diagonal A needs nothing but the lane's own slots.
+template <class V>
+struct CoopBingham {
+    using Scalar = FastBingham<1>;
+    static constexpr bool kLinear = false;
+    static constexpr int kVectors = 0;
+    static constexpr bool kQuadratic = true;
+    static constexpr bool kDistributed = false;
+    static constexpr int kScratchPerGroup = 2 * V::DPAD + 2;
+    struct Mine {};
+    __device__ __forceinline__ Mine mine_init(int) const { return Mine{}; }
+    __device__ __forceinline__ void take_au(Mine &, int, int, double) const {}
+    __device__ __forceinline__ void take_ax(Mine &, int, int, double) const {}
+    __device__ __forceinline__ void advance(Mine &, double, double) const {}
+    __device__ __forceinline__ double level_distributed(const Mine &, int, double, double) const { return 0.0; }
+    Scalar sc;
+    const double *A;     // LDS [d][DPAD]
+    const double *b;     // LDS [DPAD]
+    const double *rows;  // unused
+    int d;
+    bool diagonal;
+    __host__ __device__ static size_t lds_doubles(int d) { return (size_t)(d + 1) * V::DPAD; }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        d = tb.d;
+        diagonal = tb.k == 1;
+        lds_fill(lds, tb.d + 1, V::DPAD, tb.blob, tb.d);
+        A = lds;
+        b = lds + (size_t)tb.d * V::DPAD;
+        rows = lds;
+    }
+    __device__ __forceinline__ void make_coop(typename Scalar::Coef &cf, const double (&x)[V::N],
+                                              const double (&u)[V::N], int g, double *scratch) const
+    {
+        double qxx = 0.0, qxu = 0.0, quu = 0.0, bx = 0.0, bu = 0.0;
+        if (diagonal) {
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) {
+                const int cj = V::comp(g, j);
+                const double ajj = cj < d ? A[(size_t)cj * V::DPAD + cj] : 0.0;
+                const double xa = x[j] * ajj, ua = u[j] * ajj;
+                qxx = fma(xa, x[j], qxx);
+                qxu = fma(xa, u[j], fma(ua, x[j], qxu));
+                quu = fma(ua, u[j], quu);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) {
+                scratch[V::comp(g, j)] = x[j];
+                scratch[V::DPAD + 1 + V::comp(g, j)] = u[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double xa[V::N], ua[V::N];
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) xa[j] = ua[j] = 0.0;
+            for (int i = 0; i < d; ++i) {
+                const double xi = scratch[i], ui = scratch[V::DPAD + 1 + i];
+#pragma unroll
+                for (int j = 0; j < V::N; ++j) {
+                    const double aij = A[(size_t)i * V::DPAD + V::comp(g, j)];
+                    xa[j] = fma(xi, aij, xa[j]);
+                    ua[j] = fma(ui, aij, ua[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) {
+                qxx = fma(xa[j], x[j], qxx);
+                qxu = fma(xa[j], u[j], fma(ua[j], x[j], qxu));
+                quu = fma(ua[j], u[j], quu);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < V::N; ++j) {
+            const double bj = b[V::comp(g, j)];
+            bx = fma(bj, x[j], bx);
+            bu = fma(bj, u[j], bu);
+        }
+        cf.qxx = V::reduce(qxx);
+        cf.qxu = V::reduce(qxu);
+        cf.quu = V::reduce(quu);
+        cf.bx = V::reduce(bx);
+        cf.bu = V::reduce(bu);
+    }
+    __device__ __forceinline__ double level(const typename Scalar::Coef &cf, double c, double s) const
+    {
+        return sc.level(cf, c, s);
+    }
+    __device__ __forceinline__ double level0(typename Scalar::Coef &cf, double, bool) const { return cf.qxx + cf.bx; }
+};
+
 template <class V, class TP, bool REPLAY>
 __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, RunBlock a)
 {
@@ -839,6 +949,7 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
+    double *scratch = lds + coop_param_doubles<TP>(tb.d) + (size_t)TP::kScratchPerGroup * (threadIdx.x / V::L);
     __syncthreads();
 
     const int d = tb.d;
@@ -915,7 +1026,9 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
             for (int i = 0; i < V::N; ++i) u[i] *= rnw;
         }
         const bool refresh = (s % kCoefRefresh) == 0;
-        if constexpr (TP::kDistributed) {  // every lane keeps only the coefficients of its own segment
+        if constexpr (TP::kQuadratic) {
+            tp.make_coop(cf, x, u, g, scratch);
+        } else if constexpr (TP::kDistributed) {  // every lane keeps only the coefficients of its own segment
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 tp.take_au(my, g, r, pdot(u, r));
@@ -990,7 +1103,9 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
         if (accepted) {
 #pragma unroll
             for (int i = 0; i < V::N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
-            if constexpr (TP::kDistributed) {
+            if constexpr (TP::kQuadratic) {
+                // coefficients are rebuilt from x and u every step
+            } else if constexpr (TP::kDistributed) {
                 tp.advance(my, cs, sn);
             } else {
 #pragma unroll
@@ -1028,7 +1143,11 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
 template <class V, class TP>
 int do_coopfast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
 {
-    const size_t lds = TP::lds_doubles() * sizeof(double);
+    const size_t lds = (coop_param_doubles<TP>(tb.d) + (size_t)TP::kScratchPerGroup * (kBlock / V::L)) * sizeof(double);
+    if (lds > 160 * 1024) {
+        set_error("target parameters need %zu B of LDS", lds);
+        return GSSS_E_UNSUPPORTED;
+    }
     auto kern = replay ? coopfast_kernel<V, TP, true> : coopfast_kernel<V, TP, false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -14,6 +14,13 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
     }
     GSSS_FAST_BINGHAM_DIMS(GSSS_CASE)
 #undef GSSS_CASE
+    // larger d: lanes cooperate on one chain (A must fit the LDS: d <= 128)
+    if (tb.d > 10 && tb.d <= 128) {
+        if (probe) return GSSS_OK;
+        if (tb.d <= 16) return do_coopfast<CoopVec<4, 4>, CoopBingham<CoopVec<4, 4>>>(tb, rb, replay, st);
+        if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopBingham<CoopVec<16, 4>>>(tb, rb, replay, st);
+        return do_coopfast<CoopVec<16, 8>, CoopBingham<CoopVec<16, 8>>>(tb, rb, replay, st);
+    }
     if (!probe) set_error("fast mode is not built for a Bingham target with d=%d", tb.d);
     return GSSS_E_UNSUPPORTED;
 }

@@ -50,7 +50,8 @@ def fast_supported(z, prefix="target_"):
         k, d = z[prefix + "mu"].shape
         return (d, k) in FAST_VMF or (k in (3, 5, 10) and 10 < d <= 256)  # cooperative fast kernels
     if kind == "bingham":
-        return z[prefix + "A"].shape[0] in FAST_BINGHAM
+        d = z[prefix + "A"].shape[0]
+        return d in FAST_BINGHAM or 10 < d <= 128  # cooperative fast kernels
     if kind == "curve_vmf":
         k, d = z[prefix + "knots"].shape
         return (d, k) in FAST_CURVE or (k == 10 and 24 < d <= 512)  # cooperative fast kernels

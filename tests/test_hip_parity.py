@@ -229,9 +229,9 @@ def test_error_reporting(gs):
         gs.ShrinkageSphericalSliceSampler(pdf, np.zeros(4), 1)
     with pytest.raises(ValueError):
         pdf.log_prob(np.zeros((5, 4)))
-    zc = golden("traj_bingham_d50_vmax300.npz")
+    big = gs.Bingham(np.diag(np.arange(200.0)))
     with pytest.raises(ValueError):  # fast mode is not built for this shape: refused, no silent fallback
-        gs.ShrinkageSphericalSliceSampler(product_target(zc), zc["x0"], 1, mode="fast").advance(1)
+        gs.ShrinkageSphericalSliceSampler(big, np.eye(200)[0], 1, mode="fast").advance(1)
 
 
 def test_layout_round_trip(gs):
@@ -252,7 +252,7 @@ def test_layout_round_trip(gs):
     assert torch.equal(o, s.permute(2, 0, 1).contiguous())
 
 
-SYNTH = [("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
+SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
          ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7)]
 
 
