@@ -188,3 +188,20 @@ def test_bingham_mixing_matches_reference(gs):
     assert np.all(ratio > 0.4) and np.all(ratio < 2.5), ratio
     hop = float(gs.diagnostics.hopping_frequency(X, k["bingham_mode"]).mean())
     assert abs(hop - float(k["bingham_hop"])) < 0.35 * float(k["bingham_hop"]) + 0.002, (hop, float(k["bingham_hop"]))
+
+
+def test_bingham_d50_geodesic_step(gs):
+    """Bingham d=50, lambda_max=300 (scripts/bingham.py ind=1): the reference publishes a mean geodesic step
+    of 0.20 for geoSSS (shrink) and 1.57 for geoSSS (reject) (scripts/Bingham.ipynb:515-516)."""
+    import torch
+    pdf = gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=True, seed=6982)
+    x0 = np.repeat(np.asarray(pdf.mode)[None], 100_000, axis=0)
+    for cls, want, tol in ((gs.ShrinkageSphericalSliceSampler, 0.20, 0.015), (gs.RejectionSphericalSliceSampler, 1.57, 0.03)):
+        s = cls(pdf, x0, seed=4)
+        assert s.mode == "fast"
+        s.advance(1500 if want < 1 else 50)
+        prev = s.state_rows().clone()
+        s.advance(1)
+        assert np.all(s.errors == 0)
+        geo = torch.arccos(torch.clamp((s.state_rows() * prev).sum(1), -1, 1)).mean().item()
+        assert abs(geo - want) < tol, (cls.__name__, geo)
