@@ -10,7 +10,7 @@ mus = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, 
 pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mus])
 for n in (1, 10):
     x0 = gs.sample_sphere(2, n, seed=0).reshape(n, 3)
-    for rng, mode in (("numpy", "exact"), ("philox", "exact"), ("philox", "fast")):
+    for rng, mode in (("numpy", "exact"), ("numpy", "fast"), ("philox", "exact"), ("philox", "fast")):
         s = gs.ShrinkageSphericalSliceSampler(pdf, x0 if n > 1 else x0[0], 3521, rng=rng, mode=mode)
         s.advance(1000); torch.cuda.synchronize()
         steps = 100_000
