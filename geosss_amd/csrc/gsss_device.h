@@ -51,7 +51,7 @@ __device__ __forceinline__ size_t sample_index(const RunBlock &a, int64_t row, i
 }
 
 // ------------------------------------------------------------------------------------------
-// RNG stream (DESIGN.md "RNG stream"): Philox4x32-10, counter = (block, step_lo, chain_lo,
+// RNG stream (DESIGN.md §3 "Random streams"): Philox4x32-10, counter = (block, step_lo, chain_lo,
 // chain_hi16 | step_hi16 << 16), key = seed.  Integer part is bit-identical to the oracle.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

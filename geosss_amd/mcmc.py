@@ -14,7 +14,7 @@ convention the reference's harness feeds to its ESS estimator.
 All transitions run in the HIP kernels behind `gsss_run` (include/gsss.h); chain states stay
 resident in HBM between calls.  Two random streams:
 
-  rng="philox" (default)  the library's counter-based stream (DESIGN.md "RNG stream"), keyed by
+  rng="philox" (default)  the library's counter-based stream (DESIGN.md §3 "Random streams"), keyed by
       `seed`, chain id and step id: results do not depend on how chains are split over devices or
       steps over calls; this is the throughput path.
   rng="numpy"             numpy's own PCG64 + ziggurat stream restated on the device: a chain seeded

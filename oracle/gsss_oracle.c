@@ -209,7 +209,7 @@ void gor_logprob_batch(const gor_target *t, const double *X, int64_t n, double *
     for (int64_t i = 0; i < n; ++i) out[i] = gor_logprob(t, X + (size_t)i * t->d);
 }
 
-/* ------------------------------------------------------------------ RNG stream (DESIGN.md "RNG stream") */
+/* ------------------------------------------------------------------ RNG stream (DESIGN.md §3 "Random streams") */
 
 static void gor_philox_round(uint32_t c[4], const uint32_t k[2])
 {
