@@ -36,7 +36,7 @@
  *       scipy exactly as distributions.py:157 does.
  *   numpy PCG64/ziggurat (numpy 2.2.6)       -> three draw sources: (1) replay of a recorded
  *       stream (bit parity with the reference chain); (2) the counter-based Philox4x32-10 stream
- *       specified in DESIGN.md "RNG stream", which the HIP kernels implement identically; (3) numpy's
+ *       specified in DESIGN.md §3, which the HIP kernels implement identically; (3) numpy's
  *       own stream restated -- PCG64 XSL-RR 128/64 (numpy/random/src/pcg64/pcg64.h) feeding
  *       Generator.random / uniform / standard_normal (256-block ziggurat of
  *       numpy/random/src/distributions/distributions.c, tables read out of the installed numpy by
