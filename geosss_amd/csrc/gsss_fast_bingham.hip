@@ -3,7 +3,7 @@
 
 namespace gsss {
 
-#define GSSS_FAST_BINGHAM_DIMS(X) X(3) X(4) X(5) X(6) X(10)
+#define GSSS_FAST_BINGHAM_DIMS(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 
 int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
 {

@@ -3,7 +3,8 @@
 
 namespace gsss {
 
-#define GSSS_FAST_CURVE_DIMS(X) X(3) X(6) X(10) X(12) X(24)
+// d = 3, 6, ..., 24 is the reference's own sweep (sh/submit_job_curve_varying_ndim.sh:11); d = 10 its default
+#define GSSS_FAST_CURVE_DIMS(X) X(3) X(6) X(9) X(10) X(12) X(15) X(18) X(21) X(24)
 
 int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
 {

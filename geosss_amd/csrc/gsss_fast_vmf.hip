@@ -4,7 +4,8 @@
 
 namespace gsss {
 
-#define GSSS_FAST_VMF_SHAPES(X) X(3, 1) X(3, 2) X(3, 3) X(3, 4) X(3, 5) X(3, 10) X(4, 4) X(10, 5)
+#define GSSS_FAST_VMF_SHAPES(X) \
+    X(3, 1) X(3, 2) X(3, 3) X(3, 4) X(3, 5) X(3, 6) X(3, 8) X(3, 10) X(4, 4) X(5, 5) X(10, 3) X(10, 5) X(10, 10)
 
 int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
 {

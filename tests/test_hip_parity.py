@@ -253,7 +253,9 @@ def test_layout_round_trip(gs):
 
 
 SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
-         ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7)]
+         ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7),
+         ("curve", 9, 10), ("curve", 15, 10), ("curve", 18, 10), ("curve", 21, 10), ("bingham", 7, 0), ("bingham", 9, 0),
+         ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10)]
 
 
 @pytest.mark.parametrize("kind,d,k", SYNTH)
