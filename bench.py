@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[1]): the README 3-component vMF mixture on S^2 (kappa = 80),
 10^6 independent chains PER GPU (weak scaling; chains of rank r have ids r*10^6 ...), shrinkage
 sampler.  One bench "step" = one launch of the sampler kernel advancing every chain by
-`--inner` (default 100) MCMC transitions, keeping one thinned sample per launch; chain states
+`--inner` (default 1000) MCMC transitions, keeping one thinned sample per launch; chain states
 are resident in HBM before the timed region starts.  `value` = MCMC chain-steps per second over
 all GPUs.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -31,7 +31,7 @@ FLOPS_SETUP = {"vmfmix_readme": 240.0, "vmfmix_k10_kappa500": 324.0, "bingham_d1
 FLOPS_TRY = {"vmfmix_readme": 152.0, "vmfmix_k10_kappa500": 411.0, "bingham_d10": 48.0}
 # HBM bytes per launch from the rocprofv3 PMC passes (profiles/), corrected as MI355X_MICROARCH.md prescribes;
 # filled in from the committed profile of the default workload
-TRAFFIC_BYTES_PER_LAUNCH = {"vmfmix_readme": 2 * 19733.4e3 + 62701.2e3}  # profiles/r01_*_summary.md: 2*FETCH_SIZE + WRITE_SIZE
+TRAFFIC_BYTES_PER_LAUNCH = {"vmfmix_readme": 2 * 19724.7e3 + 62505.0e3}  # profiles/r01_*_summary.md: 2*FETCH_SIZE + WRITE_SIZE
 
 README_MUS = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
 
@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chains", type=int, default=1_000_000, help="chains per GPU")
-    ap.add_argument("--inner", type=int, default=100, help="MCMC transitions per launch (= per bench step)")
+    ap.add_argument("--inner", type=int, default=1000, help="MCMC transitions per launch (= per bench step)")
     ap.add_argument("--workload", default="vmfmix_readme")
     ap.add_argument("--thin", type=int, default=0, help="keep every thin-th state (default: one per launch)")
     ap.add_argument("--mode", default="auto")
@@ -263,7 +263,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(args.workload)
-                         if (thin == S == 100 and n == 1_000_000 and sampler.mode == "fast") else None,
+                         if (thin == S == 1000 and n == 1_000_000 and sampler.mode == "fast") else None,
                          "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                  "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
                                  "issue (see roofline_valu and DESIGN.md)"},
