@@ -25,12 +25,13 @@ def shard_bounds(n_total, rank=None, world_size=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_states(state_cm, group=None):
+def gather_states(state_cm, group=None, always_collective=False):
     """All-gather component-major states [d, n_local] -> [d, n_total] (rank order = chain order).
     Equal n_local on every rank uses one all_gather_into_tensor (a direct exchange on the fully
-    connected xGMI mesh); ragged shards fall back to all_gather of padded blocks."""
+    connected xGMI mesh); ragged shards fall back to all_gather of padded blocks.
+    A single rank returns its input unless always_collective (used to exercise the RCCL calls)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         return state_cm
     d, n_local = state_cm.shape
     sizes = torch.tensor([n_local], dtype=torch.int64, device=state_cm.device)

@@ -478,3 +478,32 @@ def test_long_chains_stay_on_the_oracle_trajectory(gs, oracle):
         s.advance(n_steps)
         assert np.array_equal(s.n_tries_per_chain, want["n_tries"]), (mode, placement)
         assert np.max(np.abs(s.state - want["state"])) < TOL, (mode, placement)
+
+
+def test_rccl_collectives_single_rank(gs):
+    """The exact collective calls of the multi-GPU path (all_gather_into_tensor, all_reduce, barrier over
+    the 'nccl' = RCCL backend, device tensors) run on this box with one rank."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from geosss_amd import ensemble
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x = gs.sample_sphere_device(2, 1000, seed=1)
+        out = ensemble.gather_states(x, always_collective=True)
+        assert out.shape == x.shape and torch.equal(out, x)
+        t = torch.tensor([5, 7], dtype=torch.int64, device="cuda")
+        assert torch.equal(ensemble.reduce_sum(t.clone()), t)
+        dist.barrier()
+        lo, hi = ensemble.shard_bounds(1000)
+        assert (lo, hi) == (0, 1000)
+        s = ensemble.sharded_sampler(gs.ShrinkageSphericalSliceSampler, product_target(golden("traj_vmfmix_readme.npz")),
+                                     5000, seed=3)
+        s.advance(5)
+        assert s.n_chains == 5000 and np.all(s.errors == 0)
+    finally:
+        dist.destroy_process_group()
