@@ -2,18 +2,26 @@
 """Benchmark of the many-chain geodesic shrinkage slice sampler on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): the README 3-component vMF mixture on S^2 (kappa = 80),
-10^6 independent chains PER GPU (weak scaling; chains of rank r have ids r*10^6 ...), shrinkage
-sampler.  One bench "step" = one launch of the sampler kernel advancing every chain by
-`--inner` (default 1000) MCMC transitions, keeping one thinned sample per launch; chain states
-are resident in HBM before the timed region starts.  `value` = MCMC chain-steps per second over
-all GPUs.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+`--gpus N > 1` without WORLD_SIZE in the environment launches N fresh ranks itself (one process per GPU
+under `python -m torch.distributed.run`, the analogue of the reference's own fan-out,
+scripts/curve_vMF.py:205-267); the parent process never touches the GPU and only relays rank 0's line
+and the exit code.  Under an external launcher (RANK / LOCAL_RANK / WORLD_SIZE set) it is a rank.
+
+Workload (BASELINE.json configs[1]): the README 3-component vMF mixture on
+S^2 (kappa = 80), 10^6 independent chains PER GPU (weak scaling; chains of rank r have ids r*10^6 ...),
+shrinkage sampler.  One bench "step" = one launch of the sampler kernel advancing every chain by
+`--inner` (default 1000) MCMC transitions, keeping every 100th state (cfg2's thinned store); chain
+states are resident in HBM before the timed region starts.  `value` = MCMC chain-steps per second over
+all GPUs.  After the headline timing, rank 0 of a single-GPU run also times <= ~1 s of each other
+BASELINE config (Bingham d=10, curve-vMF d=10/50/200, vMF mixture K=10 kappa=500) -> "configs".
+Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,24 +32,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK_TF = 78.6    # vendor vector-FP64 figure (SURVEY.md §8d)
-
-# algorithmic FP64 flops (FMA = 2) of the restricted-form algorithm, per step and per try: DESIGN.md "Roofline"
-FLOPS_SETUP = {"vmfmix_readme": 240.0, "vmfmix_k10_kappa500": 324.0, "bingham_d10": 1060.0}
-FLOPS_TRY = {"vmfmix_readme": 152.0, "vmfmix_k10_kappa500": 411.0, "bingham_d10": 48.0}
-# HBM bytes per launch from the rocprofv3 PMC passes (profiles/), corrected as MI355X_MICROARCH.md prescribes;
-# filled in from the committed profile of the default workload
-TRAFFIC_BYTES_PER_LAUNCH = {"vmfmix_readme": 2 * 19724.7e3 + 62505.0e3}  # profiles/r01_*_summary.md: 2*FETCH_SIZE + WRITE_SIZE
+FP64_VALU_PEAK_TF = 78.6    # vendor vector-FP64 figure (SURVEY.md section 8d)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # PMC HBM bytes per launch, written by tools/pmc_traffic.py
 
 README_MUS = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
+
+# (workload, chains per GPU): the BASELINE configs other than the headline one
+EXTRA_CONFIGS = [("bingham_d10", 1_000_000), ("curve_d10", 100_000), ("curve_d50", 100_000), ("curve_d200", 100_000),
+                 ("vmfmix_k10_kappa500", 1_000_000)]
 
 
 def make_target(gs, name):
     if name == "vmfmix_readme":
         return gs.MixtureModel([gs.VonMisesFisher(m) for m in README_MUS]), 3
-    if name == "vmfmix_k10_kappa500":
-        import torch  # noqa: F401
-        modes = gs.sample_sphere(2, 10, seed=1234)
+    if name == "vmfmix_k10_kappa500":  # cfg5: the reference's recipe, scripts/mixture_vMF.py:406-411
+        modes = gs.sample_sphere(2, 10, seed=1234, rng="numpy")
         return gs.MixtureModel([gs.VonMisesFisher(500.0 * m) for m in modes]), 3
     if name == "bingham_d10":
         return gs.random_bingham(d=10, vmax=30.0, vmin=0.0, eigensystem=True, seed=6982), 10
@@ -53,6 +58,30 @@ def make_target(gs, name):
         d = int(name[len("curve_d"):])
         return gs.CurvedVonMisesFisher(gs.SlerpCurve(gs.brownian_curve(10, d, 0.5, seed=4562)), 800.0), d
     raise ValueError(name)
+
+
+def algorithmic_flops(name, d, tries_per_step):
+    """FP64 flops (FMA = 2) of the restricted-form algorithm per chain-step, counted from the kernels'
+    arithmetic (DESIGN.md "Roofline"): per step the d normals (one Box-Muller pair = 80: log 40, sincos 36,
+    sqrt + scalings), the projection (3 dots, 2 axpys, 2 rsqrt-scalings = 10 d + 20), the coefficients of the
+    great circle, the level of x and log U; per try sincos (36) + the level of y(theta) + bracket update."""
+    pairs = (d + 1) // 2
+    setup = 80.0 * pairs + 10.0 * d + 20.0
+    if name.startswith("vmfmix"):
+        k = 3 if name == "vmfmix_readme" else 10
+        setup += 4.0 * k * d + 34.0 * k              # K dots with x and u; K exps for the level of x
+        if k >= 5:  # screened accept test: one double exp of the largest term, K single-precision 2^x bounds
+            per_try = 36.0 + 4.0 * k + k + 34.0 + 4.0 * k + 6.0
+        else:
+            per_try = 36.0 + 4.0 * k + 34.0 * k + 6.0  # K a_k(theta), K exps, sum, bracket
+    elif name.startswith("bingham"):
+        diag = not name.endswith("dense")
+        setup += (10.0 * d if diag else 4.0 * d * d + 8.0 * d) + 40.0  # q-coefficients; log U
+        per_try = 36.0 + 12.0 + 6.0
+    else:  # curve: 10 knots, 9 segments
+        setup += 4.0 * 10 * d + 9 * 28.0 + 40.0      # knot dots with x and u; level of x; log U
+        per_try = 36.0 + 10 * 3.0 + 9 * 28.0 + 6.0
+    return setup + tries_per_step * per_try
 
 
 def oracle_target(orc, gs, name):
@@ -96,7 +125,8 @@ def host_cores():
 
 def cpu_baseline(gs, workload, d, budget_s=12.0):
     """The CPU oracle (C restatement of the reference loop, oracle/gsss_oracle.c) timed on the
-    host cores on a bounded sample of the same workload (same target, same sampler, Philox stream)."""
+    host cores on a bounded sample of the same workload (same target, same sampler, Philox stream).
+    Runs BEFORE this process initialises the GPU (the numpy port forks worker processes)."""
     from oracle import oracle as orc
     tgt = oracle_target(orc, gs, workload)
     cores = host_cores()
@@ -149,7 +179,88 @@ def ess_per_sec(gs, pdf, d, seed, steps_per_sec_total, n_chains=512, n_draws=400
     return out
 
 
-def main():
+def measured_traffic(workload, n, S, thin, mode):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); only quoted when this
+    run's launch has the shape the profile was taken with."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))[workload]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    shape = rec.get("launch", {})
+    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode")) != (n, S, thin, mode):
+        return None, None
+    return rec["bytes_per_launch"], rec["source"]
+
+
+def hbm_bytes_per_step(d, thin, S):
+    """Algorithmic HBM bytes per chain-step: retained sample 8d/thin + state load and
+    store 16d/S + the two int64 counters read-modify-written per launch 32/S."""
+    return 8.0 * d / thin + (16.0 * d + 32.0) / S
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """N fresh child ranks under torch.distributed.run.  This parent has not imported torch and never
+    touches the GPU; rank 0's JSON line reaches stdout through the inherited pipe."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def time_config(gs, torch, name, n, S, seed=3521):
+    """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload."""
+    pdf, d = make_target(gs, name)
+    x0 = gs.sample_sphere_device(d - 1, n, seed=0)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed)
+    thin = 100
+    kept = torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda")
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    s.advance(100)                                   # warm-up: 100 transitions (cfg: "warm-up 100 steps")
+    b.record()
+    torch.cuda.synchronize()
+    reps = int(max(1, min(10, 1.0 / max(1e-4, a.elapsed_time(b) * 1e-3 * S / 100))))
+    tries0 = int(s._n_tries.sum().item())
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        s.advance(S, thin=thin, out=kept)
+        b.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    tps = (int(s._n_tries.sum().item()) - tries0) / (n * S * reps)
+    lib = gs._lib.load()
+    mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
+    bytes_launch = hbm_bytes_per_step(d, thin, S) * n * S
+    flops = algorithmic_flops(name, d, tps)
+    traffic, src = measured_traffic(name, n, S, thin, s.mode)
+    return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}",
+            "value": n * S * reps / dt, "unit": "chain-steps/s", "launches": reps, "mode": s.mode,
+            "kernel": lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(),
+            "kernel_ms": kern_ms, "tries_per_step": tps, "chains_in_error": int((s._err != 0).sum().item()),
+            "roofline": {"bound": "hbm", "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": src},
+            "roofline_valu": {"bound": "fp64_valu", "achieved": flops * n * S / (kern_ms * 1e-3) / 1e12,
+                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": flops * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                              "flops_per_chain_step": flops}}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -157,22 +268,35 @@ def main():
     ap.add_argument("--chains", type=int, default=1_000_000, help="chains per GPU")
     ap.add_argument("--inner", type=int, default=1000, help="MCMC transitions per launch (= per bench step)")
     ap.add_argument("--workload", default="vmfmix_readme")
-    ap.add_argument("--thin", type=int, default=0, help="keep every thin-th state (default: one per launch)")
+    ap.add_argument("--thin", type=int, default=100, help="keep every thin-th state (cfg2: every 100th)")
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0")
 
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return self_launch(args, argv)              # nothing below has run: no torch, no HIP in this process
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n")
+        return 2
+
+    import geosss_amd as gs                          # imports torch; does not initialise the GPU
+    pdf, d = make_target(gs, args.workload)
+    # CPU baseline first: rank 0 of a single-GPU run, before this process holds a HIP context
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(gs, args.workload, d)
+
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # one process per GPU; GSSS_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the
     # multi-rank code path on a single-GPU box (RCCL refuses two ranks on one device)
@@ -186,18 +310,17 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import geosss_amd as gs
     from geosss_amd.ensemble import gather_states
 
-    pdf, d = make_target(gs, args.workload)
     n = args.chains
     chain_offset = rank * n
     x0 = gs.sample_sphere_device(d - 1, n, seed=0, chain_offset=chain_offset)  # [d, n] on device
     sampler = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=3521, chain_offset=chain_offset, mode=args.mode,
                                                 variant=args.variant)
     S = args.inner
-    thin = args.thin or S
+    thin = min(args.thin, S) if args.thin > 0 else S
     kept = torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda")
+    counts = [n] * world                             # chains per rank are fixed: no size exchange per gather
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,8 +330,19 @@ def main():
 
     for _ in range(args.warmup):
         sampler.advance(S, thin=thin, out=kept)
+    rccl = {"ranks_seen": 1, "backend": None, "gather_ms": 0.0}
     if world > 1:  # the collective's lazy channel setup must not land inside the timed region
-        gather_states(sampler.state_device)
+        gather_states(sampler.state_device, counts=counts)
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones)                        # every rank contributes 1: proves N live ranks on the backend
+        barrier()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        gather_states(sampler.state_device, counts=counts)
+        g1.record()
+        torch.cuda.synchronize()
+        rccl = {"ranks_seen": int(ones.item()), "backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend,
+                "gather_ms": float(g0.elapsed_time(g1)), "gather_bytes_per_rank": 8 * d * n}
     tries0 = int(sampler._n_tries.sum().item())
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
@@ -217,7 +351,7 @@ def main():
         a.record()
         sampler.advance(S, thin=thin, out=kept)
         b.record()
-    final = gather_states(sampler.state_device) if world > 1 else sampler.state_device
+    final = gather_states(sampler.state_device, counts=counts) if world > 1 else sampler.state_device
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -238,15 +372,12 @@ def main():
     value = total_steps / elapsed
 
     if rank == 0:
-        # algorithmic HBM bytes per chain-step (DESIGN.md "Roofline"): retained sample 8d/thin (thin = S here)
-        # + state load/store 16d/S + per-chain counters (two int64 read-modify-writes = 32 B) / S
-        bytes_per_step = 8.0 * d / thin + (16.0 * d + 32.0) / S
-        bytes_per_launch = bytes_per_step * n * S
+        bytes_per_launch = hbm_bytes_per_step(d, thin, S) * n * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
-        # algorithmic FP64 flops per chain-step (DESIGN.md "Roofline"): setup + tries x per-try
-        flops_step = FLOPS_SETUP.get(args.workload, 0.0) + (tries / total_steps) * FLOPS_TRY.get(args.workload, 0.0)
+        flops_step = algorithmic_flops(args.workload, d, tries / total_steps)
+        traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode)
         out = {
             "metric": "mcmc_chain_steps_per_sec", "value": value, "unit": "chain-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -255,15 +386,13 @@ def main():
                                    "launch, thin=%d, Philox4x32-10 stream" % thin,
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S,
                        "mode": sampler.mode,
-                       "kernel": lib.gsss_variant_name(sampler._target_dev.handle, mode_id, args.variant).decode(),
+                       "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
                        "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"
                        if world > 1 else "single GPU"},
             "tries_per_step": tries / total_steps, "chains_in_error": bad,
-            "kernel_ms": kern_ms,
+            "kernel_ms": kern_ms, "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(args.workload)
-                         if (thin == S == 1000 and n == 1_000_000 and sampler.mode == "fast") else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                  "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
                                  "issue (see roofline_valu and DESIGN.md)"},
@@ -272,14 +401,18 @@ def main():
                               "frac": flops_step * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
                               "flops_per_chain_step": flops_step},
         }
+        if world == 1 and not args.no_configs and args.workload == "vmfmix_readme":
+            del sampler, kept
+            out["configs"] = [time_config(gs, torch, name, nc, S) for name, nc in EXTRA_CONFIGS]
         if world == 1 and not args.no_ess:
             out["ess"] = ess_per_sec(gs, pdf, d, 3521, value)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gs, args.workload, d)
-        print(json.dumps(out))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libgsss_hip.so")
 VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
 SHRINK, REJECT = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
-CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED = 1, 2, 4
+CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
 ABI_VERSION = 4
 
 
@@ -45,6 +45,7 @@ SIGNATURES = {
     "gsss_run": (C.c_int, [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]),
     "gsss_mode_supported": (C.c_int, [C.c_void_p, C.c_int32]),
     "gsss_variant_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
+    "gsss_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "gsss_sample_sphere": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "gsss_rows_to_components": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),
     "gsss_components_to_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),

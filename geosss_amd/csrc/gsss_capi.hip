@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
 
 }  // namespace gsss
 
-static int fast_dispatch(const gsss::TargetBlock &tb, const gsss::RunBlock &rb, bool replay, bool probe,
+static int fast_dispatch(const gsss::TargetBlock &tb, const gsss::RunBlock &rb, bool replay, gsss::FastProbe *probe,
                          hipStream_t st)
 {
     switch (tb.kind) {
@@ -491,7 +491,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
             set_error("fast mode takes at most 2^31-1 steps / chains per call");
             return GSSS_E_INVALID;
         }
-        return fast_dispatch(t->tb, rb, replay, false, st);
+        return fast_dispatch(t->tb, rb, replay, nullptr, st);
     }
     switch (t->tb.kind) {
     case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, draws, t->tb, rb, st);
@@ -506,7 +506,10 @@ int gsss_mode_supported(const gsss_target *t, int32_t mode)
 {
     if (!t) return 0;
     if (mode == GSSS_MODE_EXACT) return select_vec(t->tb.d, 0) >= 0;
-    if (mode == GSSS_MODE_FAST) return fast_dispatch(t->tb, RunBlock{}, false, true, nullptr) == GSSS_OK;
+    if (mode == GSSS_MODE_FAST) {
+        FastProbe pr;
+        return fast_dispatch(t->tb, RunBlock{}, false, &pr, nullptr) == GSSS_OK;
+    }
     return 0;
 }
 
@@ -514,9 +517,9 @@ const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t varian
 {
     if (!t) return "";
     if (mode == GSSS_MODE_FAST) {
-        if (!gsss_mode_supported(t, mode)) return "";
-        const bool lane = t->tb.kind == GSSS_CURVE_VMF ? t->tb.d <= 24 : t->tb.d <= 10;
-        return lane ? "fast-lane" : "fast-coop";
+        FastProbe pr;
+        if (fast_dispatch(t->tb, RunBlock{}, false, &pr, nullptr) != GSSS_OK) return "";
+        return pr.lane ? "fast-lane" : "fast-coop";
     }
     const int vec = select_vec(t->tb.d, variant);
     if (vec < 0) return "";
@@ -525,6 +528,27 @@ const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t varian
     for (int i = 0; i < n; ++i)
         if (v[i].id == vec) return v[i].name;
     return "";
+}
+
+const char *gsss_kernel_name(const gsss_target *t, int32_t mode, int32_t variant, int32_t placement)
+{
+    static thread_local char name[200];
+    name[0] = 0;
+    if (!t) return name;
+    const bool spread = placement == 2;
+    if (mode == GSSS_MODE_FAST) {
+        FastProbe pr;
+        if (fast_dispatch(t->tb, RunBlock{}, false, &pr, nullptr) != GSSS_OK) return name;
+        if (pr.lane && spread && t->tb.d <= 16)
+            snprintf(name, sizeof(name), "wave_kernel%s", strchr(pr.name, '<') ? strchr(pr.name, '<') : "");
+        else
+            snprintf(name, sizeof(name), "%s", pr.name);
+        return name;
+    }
+    const char *vec = gsss_variant_name(t, mode, variant);
+    const char *tgt = t->tb.kind == GSSS_VMF_MIXTURE ? "VmfMixture" : (t->tb.kind == GSSS_BINGHAM ? "Bingham" : "CurveVmf");
+    if (vec[0]) snprintf(name, sizeof(name), "run_kernel<%s, %s>", vec, tgt);
+    return name;
 }
 
 int gsss_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int32_t d, double *state_dev, int device,

@@ -24,12 +24,15 @@
 // Elementary functions come from gsss_math.h (bounded-range sincos, Taylor exp).  Results agree
 // with the reference to ~1e-14 per step; tests hold them to 1e-10 against the golden chains.
 #pragma once
+#include <stdio.h>
+
 #include "gsss_device.h"
 #include "gsss_math.h"
 
 namespace gsss {
 
 enum : int32_t { kReady = 0, kPending = 1, kDone = 2 };
+constexpr double kLogZero = -1.0e5;  // stands in for log(0) where the arithmetic must stay finite
 
 // 1 / (sqrt(s) + 1e-100) of sphere.py:14 as one reciprocal square root; the 1e-100 only matters for
 // the zero vector, whose projection the reference maps to zero
@@ -65,7 +68,10 @@ struct FastVmf {
     __host__ __device__ static size_t lds_doubles() { return (size_t)KC * D + KC; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
-        for (int i = threadIdx.x; i < KC * D + KC; i += kBlock) lds[i] = tb.blob[i];
+        for (int i = threadIdx.x; i < KC * D; i += kBlock) lds[i] = tb.blob[i];
+        // a zero-weight component has logc = -inf (log w_k, distributions.py:220); exp_bounded wants finite
+        // arguments, and e^{-1e5} is as much a zero as e^{-inf}
+        for (int i = threadIdx.x; i < KC; i += kBlock) lds[KC * D + i] = fmax(tb.blob[KC * D + i], kLogZero);
         mu = lds;
         logc = lds + KC * D;
     }
@@ -413,6 +419,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
 
     auto count_tries = [&]() {
         const uint32_t sum = cur.n_try + (uint32_t)cur.t;
+        if (sum < cur.n_try) cur.err |= GSSS_CHAIN_COUNTER_SATURATED;  // > 2^32-1 proposals in one launch
         cur.n_try = sum < cur.n_try ? 0xFFFFFFFFu : sum;
     };
     auto init = [&]() {
@@ -561,12 +568,12 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         }
         // (n_try, t | status << 26 | err << 28); the status also stays in a register for the wave-level votes
         const int32_t st = cur.status;
-        int32_t nt = (int32_t)cur.n_try, packed = cur.t | (cur.status << 26) | (cur.err << 28);
+        int32_t nt = (int32_t)cur.n_try, packed = cur.t | (cur.status << 26) | (int32_t)((uint32_t)cur.err << 28);
         lds_trade(nt, packed, p);
         cur.n_try = (uint32_t)nt;
         cur.t = packed & 0x3FFFFFF;
         cur.status = (packed >> 26) & 3;
-        cur.err = (packed >> 28) & 7;
+        cur.err = (int32_t)((uint32_t)packed >> 28);
         parked_status = st;
         slot ^= 1;
     };
@@ -609,7 +616,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         put(cur.lvl);
         put2(cur.steps_done, cur.row);
         if (REPLAY) put2(cur.cursor, 0);
-        put2((int32_t)cur.n_try, cur.t | (cur.status << 26) | (cur.err << 28));
+        put2((int32_t)cur.n_try, cur.t | (cur.status << 26) | (int32_t)((uint32_t)cur.err << 28));
         parked_status = cur.status;
     }
     slot = 0;
@@ -676,14 +683,28 @@ int do_fast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t 
     if constexpr (D <= 16) {
         if (rb.spread) return do_wave<D, TP>(tb, rb, st);  // small ensemble: one wavefront per chain
     }
+    if (rb.rng_state != nullptr) {  // only the wave kernel reads numpy's stream
+        set_error("in fast mode the numpy stream needs spread placement and d <= 16; use GSSS_MODE_EXACT");
+        return GSSS_E_UNSUPPORTED;
+    }
     return do_fast_run<D, TP, false>(tb, rb, st);
 }
 
 // per-target entry points (one translation unit each); GSSS_E_UNSUPPORTED when no instantiation
-// covers (d, k).  `probe` = only answer whether a kernel exists.
-int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
-int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
-int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st);
+// covers (d, k).  `probe` != nullptr: launch nothing, only answer whether a kernel exists and name it.
+struct FastProbe {
+    char name[160];  // the instantiation that would run, e.g. "fast_kernel<3, FastVmf<3, 3>>"
+    bool lane;       // lane-per-chain layout (small ensembles then run wave_kernel of the same shape)
+};
+int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st);
+int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st);
+int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st);
+#define GSSS_PROBE(LANE, ...)                                         \
+    do {                                                              \
+        snprintf(probe->name, sizeof(probe->name), __VA_ARGS__);      \
+        probe->lane = LANE;                                           \
+        return GSSS_OK;                                               \
+    } while (0)
 
 }  // namespace gsss
 
@@ -821,7 +842,7 @@ struct CoopVmf {
     {
         lds_fill(lds, KC, V::DPAD, tb.blob, tb.d);
         double *lc = lds + (size_t)KC * V::DPAD;
-        for (int i = threadIdx.x; i < KC; i += kBlock) lc[i] = tb.blob[(size_t)KC * tb.d + i];
+        for (int i = threadIdx.x; i < KC; i += kBlock) lc[i] = fmax(tb.blob[(size_t)KC * tb.d + i], kLogZero);
         rows = lds;
         sc.mu = lds;
         sc.logc = lc;
@@ -1143,6 +1164,11 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
 template <class V, class TP>
 int do_coopfast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
 {
+    if (rb.rng_state != nullptr) {  // the cooperative fast kernels draw from Philox only
+        set_error("in fast mode the numpy stream is served for lane-per-chain shapes only (this shape runs the "
+                  "cooperative fast kernel); use GSSS_MODE_EXACT");
+        return GSSS_E_UNSUPPORTED;
+    }
     const size_t lds = (coop_param_doubles<TP>(tb.d) + (size_t)TP::kScratchPerGroup * (kBlock / V::L)) * sizeof(double);
     if (lds > 160 * 1024) {
         set_error("target parameters need %zu B of LDS", lds);

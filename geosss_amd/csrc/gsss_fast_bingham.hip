@@ -5,18 +5,19 @@ namespace gsss {
 
 #define GSSS_FAST_BINGHAM_DIMS(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 
-int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
+int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
 {
 #define GSSS_CASE(D)                                               \
     if (tb.d == D) {                                               \
-        if (probe) return GSSS_OK;                                 \
+        if (probe) GSSS_PROBE(true, "fast_kernel<%d, FastBingham<%d>>", D, D); \
         return do_fast<D, FastBingham<D>>(tb, rb, replay, st);     \
     }
     GSSS_FAST_BINGHAM_DIMS(GSSS_CASE)
 #undef GSSS_CASE
     // larger d: lanes cooperate on one chain (A must fit the LDS: d <= 128)
     if (tb.d > 10 && tb.d <= 128) {
-        if (probe) return GSSS_OK;
+        if (probe)
+            GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopBingham>", tb.d <= 16 ? 4 : 16, tb.d <= 64 ? 4 : 8);
         if (tb.d <= 16) return do_coopfast<CoopVec<4, 4>, CoopBingham<CoopVec<4, 4>>>(tb, rb, replay, st);
         if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopBingham<CoopVec<16, 4>>>(tb, rb, replay, st);
         return do_coopfast<CoopVec<16, 8>, CoopBingham<CoopVec<16, 8>>>(tb, rb, replay, st);

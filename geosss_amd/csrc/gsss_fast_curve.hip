@@ -6,18 +6,19 @@ namespace gsss {
 // d = 3, 6, ..., 24 is the reference's own sweep (sh/submit_job_curve_varying_ndim.sh:11); d = 10 its default
 #define GSSS_FAST_CURVE_DIMS(X) X(3) X(6) X(9) X(10) X(12) X(15) X(18) X(21) X(24)
 
-int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
+int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
 {
 #define GSSS_CASE(D)                                                \
     if (tb.d == D && tb.k == 10) {                                  \
-        if (probe) return GSSS_OK;                                  \
+        if (probe) GSSS_PROBE(true, "fast_kernel<%d, FastCurve<%d, 10>>", D, D); \
         return do_fast<D, FastCurve<D, 10>>(tb, rb, replay, st);    \
     }
     GSSS_FAST_CURVE_DIMS(GSSS_CASE)
 #undef GSSS_CASE
     // larger d: lanes cooperate on one chain
     if (tb.k == 10 && tb.d > 24 && tb.d <= 512) {
-        if (probe) return GSSS_OK;
+        if (probe)
+            GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopCurve<10>>", tb.d <= 64 ? 16 : 64, tb.d <= 256 ? 4 : 8);
         if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopCurve<CoopVec<16, 4>, 10>>(tb, rb, replay, st);
         if (tb.d <= 256) return do_coopfast<CoopVec<64, 4>, CoopCurve<CoopVec<64, 4>, 10>>(tb, rb, replay, st);
         return do_coopfast<CoopVec<64, 8>, CoopCurve<CoopVec<64, 8>, 10>>(tb, rb, replay, st);

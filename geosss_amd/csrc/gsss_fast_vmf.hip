@@ -7,11 +7,11 @@ namespace gsss {
 #define GSSS_FAST_VMF_SHAPES(X) \
     X(3, 1) X(3, 2) X(3, 3) X(3, 4) X(3, 5) X(3, 6) X(3, 8) X(3, 10) X(4, 4) X(5, 5) X(10, 3) X(10, 5) X(10, 10)
 
-int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool probe, hipStream_t st)
+int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
 {
 #define GSSS_CASE(D, K)                                            \
     if (tb.d == D && tb.k == K) {                                  \
-        if (probe) return GSSS_OK;                                 \
+        if (probe) GSSS_PROBE(true, "fast_kernel<%d, FastVmf<%d, %d>>", D, D, K); \
         return do_fast<D, FastVmf<D, K>>(tb, rb, replay, st);      \
     }
     GSSS_FAST_VMF_SHAPES(GSSS_CASE)
@@ -19,7 +19,8 @@ int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, bool
     // larger d: lanes cooperate on one chain (K = 3, 5 or 10 components)
 #define GSSS_COOP(K)                                                                                          \
     if (tb.k == K && tb.d > 10 && tb.d <= 256) {                                                              \
-        if (probe) return GSSS_OK;                                                                            \
+        if (probe)                                                                                            \
+            GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, 4>, CoopVmf<%d>>", tb.d <= 16 ? 4 : (tb.d <= 64 ? 16 : 64), K); \
         if (tb.d <= 16) return do_coopfast<CoopVec<4, 4>, CoopVmf<CoopVec<4, 4>, K>>(tb, rb, replay, st);     \
         if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopVmf<CoopVec<16, 4>, K>>(tb, rb, replay, st);   \
         return do_coopfast<CoopVec<64, 4>, CoopVmf<CoopVec<64, 4>, K>>(tb, rb, replay, st);                   \

@@ -25,19 +25,33 @@ def shard_bounds(n_total, rank=None, world_size=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_states(state_cm, group=None, always_collective=False):
+def gather_states(state_cm, group=None, always_collective=False, counts=None):
     """All-gather component-major states [d, n_local] -> [d, n_total] (rank order = chain order).
-    Equal n_local on every rank uses one all_gather_into_tensor (a direct exchange on the fully
-    connected xGMI mesh); ragged shards fall back to all_gather of padded blocks.
+
+    `counts` = chains per rank, when the caller knows them (they are fixed for an ensemble: pass them and no
+    size exchange or host synchronisation happens per call).  Equal shards of a small d gather each
+    component row straight into its row of the result -- d all_gather_into_tensor calls (direct exchanges on
+    the fully connected xGMI mesh), no transposes, no staging copies; large d gathers rows once and
+    transposes once; ragged shards fall back to all_gather of padded blocks.
     A single rank returns its input unless always_collective (used to exercise the RCCL calls)."""
     rank, ws = world()
     if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         return state_cm
     d, n_local = state_cm.shape
-    sizes = torch.tensor([n_local], dtype=torch.int64, device=state_cm.device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(ws)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    counts = [int(s.item()) for s in all_sizes]
+    if counts is None:
+        sizes = torch.tensor([n_local], dtype=torch.int64, device=state_cm.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(ws)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        counts = [int(s.item()) for s in all_sizes]
+    counts = [int(c) for c in counts]
+    if len(counts) != ws or counts[rank] != n_local:
+        raise ValueError("counts must list the chains of every rank")
+    if len(set(counts)) == 1 and d <= 16:
+        state_cm = state_cm.contiguous()
+        out = torch.empty((d, ws * n_local), dtype=state_cm.dtype, device=state_cm.device)
+        for j in range(d):
+            dist.all_gather_into_tensor(out[j], state_cm[j], group=group)
+        return out
     rows = state_cm.t().contiguous()  # [n_local, d]: concatenation over ranks is then contiguous
     if len(set(counts)) == 1:
         out = torch.empty((ws * n_local, d), dtype=rows.dtype, device=rows.device)

@@ -23,7 +23,9 @@ resident in HBM between calls.  Two random streams:
       output from the seed alone (to rounding, ~1e-14).  For one chain `sampler.rng` is kept in
       step with the device stream, as the reference's attribute would be.
 """
+import copy
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -60,13 +62,27 @@ def seed_to_key(seed):
         w = np.random.SeedSequence(int(seed)).generate_state(2, np.uint32)
     elif isinstance(seed, np.random.SeedSequence):
         w = seed.generate_state(2, np.uint32)
-    elif isinstance(seed, np.random.Generator):
-        w = seed.integers(0, 2**32, size=2, dtype=np.uint64)
-    elif isinstance(seed, np.random.BitGenerator):
-        w = np.random.Generator(seed).integers(0, 2**32, size=2, dtype=np.uint64)
+    elif isinstance(seed, (np.random.Generator, np.random.BitGenerator)):
+        # the key is drawn from a COPY: the caller's generator (kept as sampler.rng) is not advanced
+        g = copy.deepcopy(seed)
+        g = g if isinstance(g, np.random.Generator) else np.random.Generator(g)
+        w = g.integers(0, 2**32, size=2, dtype=np.uint64)
     else:
         w = np.random.SeedSequence(seed).generate_state(2, np.uint32)
     return int(w[0]) | (int(w[1]) << 32)
+
+
+_warned_shapes = set()
+
+
+def _warn_exact_fallback(distribution):
+    """mode='auto' landed on the generic (exact) kernels: say so once per target shape."""
+    key = (type(distribution).__name__, distribution.d)
+    if key in _warned_shapes:
+        return
+    _warned_shapes.add(key)
+    warnings.warn(f"geosss_amd: no fast-mode kernel covers this {key[0]} target (d={key[1]}); mode='auto' uses the "
+                  "exact kernels (2.5-10x lower throughput; see gsss_mode_supported)", RuntimeWarning, stacklevel=3)
 
 
 class RejectionSphericalSliceSampler:
@@ -76,17 +92,20 @@ class RejectionSphericalSliceSampler:
 
     def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="auto", max_tries=None,
                  chain_offset=0, step_offset=0, variant=0, rng="philox", placement="auto"):
+        if rng not in ("philox", "numpy"):
+            raise ValueError("rng must be 'philox' or 'numpy'")
+        if placement not in ("auto", "packed", "spread"):
+            raise ValueError("placement must be 'auto', 'packed' or 'spread'")
+        many_seeds = isinstance(seed, (list, tuple))
+        if many_seeds and rng != "numpy":
+            raise ValueError("a list of seeds (one numpy generator per chain) needs rng='numpy'; the Philox stream "
+                             "takes one seed and keys every chain by its global chain id")
         _lib.require_device()
         self._lib = _lib.load()
         self.target = distribution
-        if rng not in ("philox", "numpy"):
-            raise ValueError("rng must be 'philox' or 'numpy'")
         self.rng_kind = rng
-        if placement not in ("auto", "packed", "spread"):
-            raise ValueError("placement must be 'auto', 'packed' or 'spread'")
         self._placement = {"auto": 0, "packed": 1, "spread": 2}[placement]
         self._seed_arg = seed
-        many_seeds = isinstance(seed, (list, tuple))
         self.rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(
             seed[0] if many_seeds else seed)
         self.seed = 0 if rng == "numpy" else seed_to_key(seed[0] if many_seeds else seed)
@@ -104,7 +123,7 @@ class RejectionSphericalSliceSampler:
         if rng == "numpy":
             # sequential per chain: fast mode serves it with the one-wavefront-per-chain kernel only
             wave_ok = (self._placement != 1 and self.n_chains <= 2048 and distribution.d <= 16 and not variant and
-                       self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST))
+                       self._lib.gsss_variant_name(self._target_dev.handle, _lib.MODE_FAST, 0) == b"fast-lane")
             if mode == "fast" and not wave_ok:
                 raise ValueError("rng='numpy' in fast mode needs a small ensemble (<= 2048 chains, spread placement) "
                                  "of a shape the fast kernels are built for; use mode='exact' or 'auto'")
@@ -115,6 +134,8 @@ class RejectionSphericalSliceSampler:
         if mode == "auto":  # the throughput kernels where they are built for this shape, else the generic ones
             fast_ok = self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST) and not variant
             self.mode = "fast" if fast_ok else "exact"
+            if not fast_ok and not variant:
+                _warn_exact_fallback(distribution)
         n = self.n_chains
         self._n_reject = torch.zeros(n, dtype=torch.int64, device=self._tdev)
         self._n_tries = torch.zeros(n, dtype=torch.int64, device=self._tdev)
@@ -236,7 +257,7 @@ class RejectionSphericalSliceSampler:
         if bad:
             bits = int(self._err.max().item())
             raise _lib.GsssError(f"{bad} chain(s) stopped with error bits (max {bits}): "
-                                 "1=max_tries, 2=non-finite log_prob, 4=replay exhausted")
+                                 "1=max_tries, 2=non-finite log_prob, 4=replay exhausted, 8=try counter saturated")
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):

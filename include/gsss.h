@@ -58,6 +58,8 @@ extern "C" {
 #define GSSS_CHAIN_MAX_TRIES 1        /* shrink/reject loop hit max_tries; state left at x */
 #define GSSS_CHAIN_NONFINITE 2        /* log_prob(state) was -inf/NaN (reference would spin forever, mcmc.py:394) */
 #define GSSS_CHAIN_REPLAY_EXHAUSTED 4 /* replay stream shorter than the draws consumed */
+#define GSSS_CHAIN_COUNTER_SATURATED 8 /* fast mode counts the proposals of ONE launch in 32 bits: more than 2^32-1 of them
+                                          in a single gsss_run call leave n_tries/n_reject too small (split the call) */
 
 typedef struct gsss_target gsss_target; /* opaque; owns a small device parameter block */
 
@@ -153,6 +155,10 @@ int gsss_mode_supported(const gsss_target *t, int32_t mode);
 
 /* Names the kernel variant gsss_run would use / the variants available, for logs and benches. */
 const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t variant);
+/* The kernel instantiation gsss_run launches for this target (what a rocprofv3 kernel trace shows, template arguments
+ * abbreviated), e.g. "fast_kernel<3, FastVmf<3, 3>>"; placement as in gsss_run_args (2 = spread).  "" if unsupported.
+ * The string lives in thread-local storage until the thread's next call. */
+const char *gsss_kernel_name(const gsss_target *t, int32_t mode, int32_t variant, int32_t placement);
 
 /* sphere.sample_sphere twin (sphere.py:39-50): n uniform points on S^{d-1}, component-major,
  * from the reserved step id of the RNG stream. */

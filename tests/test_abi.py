@@ -50,7 +50,7 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(GsssError):
         gs.ShrinkageSphericalSliceSampler(pdf, np.array([0.0, 0.0, 1.0]), 1)
     with pytest.raises(GsssError):
-        gs.sample_sphere(2, 4, seed=0)
+        gs.sample_sphere(2, 4, seed=0, rng="philox")
 
 
 def test_target_construction_matches_reference_recipes():
@@ -96,3 +96,37 @@ def test_call_counter_protocol():
     assert pdf.log_prob.num_calls == 0  # reachable through the bound method, as scripts do
     # separate counters per class, like the reference's per-class decoration
     assert gs.Bingham.log_prob is not gs.MixtureModel.log_prob
+
+
+def test_sample_sphere_is_the_reference_recipe():
+    """gs.sample_sphere(d, size, seed) = radial_projection(default_rng(seed).standard_normal(...)) as in
+    geosss/sphere.py:39-50: the reference's target recipes build the reference's arrays (fixtures hold them)."""
+    import geosss_amd as gs
+    from conftest import golden
+    z = golden("traj_vmfmix_k10_kappa500.npz")          # modes = sample_sphere(2, 10, seed=1234) * 500
+    assert np.array_equal(500.0 * gs.sample_sphere(2, 10, seed=1234), z["target_mu"])
+    assert np.array_equal(gs.sample_sphere(2, seed=1345), z["x0"])
+    for name, d in (("traj_curve_d10_kappa800.npz", 10), ("traj_curve_d50_kappa800.npz", 50),
+                    ("traj_curve_d200_kappa800.npz", 200)):
+        assert np.array_equal(gs.sample_sphere(d - 1, seed=1345), golden(name)["x0"])   # scripts/curve_vMF.py:577-589
+    x = gs.sample_sphere(4, 7, seed=3)
+    g = np.random.default_rng(3).standard_normal((7, 5))
+    assert np.array_equal(x, g / (np.linalg.norm(g, axis=-1) + 1e-100)[:, None])
+    with pytest.raises(ValueError):
+        gs.sample_sphere(2, 4, seed=0, rng="pcg")
+
+
+def test_seed_argument_handling():
+    """Seeds are never silently reinterpreted: a list of seeds is refused for the Philox stream, and a Generator
+    handed over as seed is not advanced by deriving the key from it."""
+    import geosss_amd as gs
+    from geosss_amd.mcmc import seed_to_key
+    g = np.random.default_rng(5)
+    before = g.bit_generator.state
+    k1, k2 = seed_to_key(g), seed_to_key(g)
+    assert k1 == k2 and g.bit_generator.state == before
+    pdf = gs.MixtureModel([gs.VonMisesFisher([0.0, 0.0, 5.0])])
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, np.eye(3), [1, 2, 3])
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, np.eye(3), 1, rng="mt19937")

@@ -507,3 +507,90 @@ def test_rccl_collectives_single_rank(gs):
         assert s.n_chains == 5000 and np.all(s.errors == 0)
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ round-2 regressions
+
+
+@pytest.mark.parametrize("kind", ["bingham_d12", "bingham_d12_dense", "vmfmix_d12_k3", "vmfmix_d14_k5"])
+def test_numpy_stream_on_cooperative_fast_shapes(gs, oracle, kind):
+    """Shapes whose fast path is the COOPERATIVE kernel (10 < d <= 16) cannot read numpy's stream: mode='auto'
+    must fall back to the exact kernels and reproduce the oracle's numpy-stream chains from the seeds, and
+    mode='fast' (Python and C ABI) must refuse instead of silently drawing from Philox."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    if kind.startswith("bingham"):
+        d = 12
+        pdf = gs.random_bingham(d=d, vmax=25.0, vmin=0.0, eigensystem=not kind.endswith("dense"), seed=4)
+        tgt = oracle.Target.bingham(pdf.A)
+    else:
+        d, k = (12, 3) if kind == "vmfmix_d12_k3" else (14, 5)
+        mus = 40.0 * gs.sample_sphere(d - 1, k, seed=8)
+        pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mus], rng.uniform(0.5, 2.0, k))
+        tgt = oracle.Target.vmf_mixture(mus, pdf.weights)
+    n, steps = 24, 20
+    seeds = list(np.random.SeedSequence(777).spawn(n))
+    x0 = oracle.sample_sphere(3, n, d)
+    want = oracle.run(tgt, x0, steps, numpy_seed=seeds)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, np.random.SeedSequence(777), rng="numpy")
+    assert s.mode == "exact"
+    got = s.advance(steps, thin=1).permute(2, 0, 1).cpu().numpy()
+    assert np.max(np.abs(got - want["samples"])) < TOL
+    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    assert np.array_equal(s._rng_state.cpu().numpy().view(np.uint64)[:, :2], want["pcg"][:, :2])
+    # one chain, from an int seed: two different seeds give two different chains (the advisor's symptom was one chain for all)
+    a = gs.ShrinkageSphericalSliceSampler(pdf, x0[0], 1, rng="numpy").sample(6)
+    b = gs.ShrinkageSphericalSliceSampler(pdf, x0[0], 2, rng="numpy").sample(6)
+    assert not np.allclose(a[1:], b[1:])
+    with pytest.raises(ValueError):
+        gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, rng="numpy", mode="fast")
+    # C ABI: fast mode + rng_state_dev on this shape is GSSS_E_UNSUPPORTED, in both placements
+    from geosss_amd import _lib
+    lib = _lib.load()
+    for placement in (1, 2):
+        args = _lib.RunArgs()
+        args.state_dev = s._state.data_ptr()
+        args.n_chains, args.n_steps, args.thin, args.max_tries = n, 1, 1, 1000
+        args.mode, args.sampler, args.placement = _lib.MODE_FAST, _lib.SHRINK, placement
+        args.rng_state_dev = s._rng_state.data_ptr()
+        assert lib.gsss_run(s._target_dev.handle, C.byref(args), None) == -2
+        assert b"numpy stream" in lib.gsss_last_error()
+
+
+@pytest.mark.parametrize("d,k", [(3, 3), (3, 5), (3, 10), (10, 5), (12, 3)])
+def test_zero_weight_component_in_fast_mode(gs, oracle, d, k):
+    """A mixture weight of zero (log w = -inf, distributions.py:220; scipy's logsumexp ignores the term) must not
+    poison the fast kernels' exponentials: fast == exact == oracle."""
+    mus = 30.0 * gs.sample_sphere(d - 1, k, seed=21)
+    w = np.ones(k)
+    w[1] = 0.0
+    pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mus], w)
+    tgt = oracle.Target.vmf_mixture(mus, w)
+    n, steps = 333, 30
+    x0 = oracle.sample_sphere(5, n, d)
+    want = oracle.run(tgt, x0, steps, seed=9, n_threads=8)
+    for placement in ("packed", "spread"):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=9, mode="fast", placement=placement)
+        got = s.advance(steps, thin=1).permute(2, 0, 1).cpu().numpy()
+        assert np.all(s.errors == 0)
+        assert np.max(np.abs(got - want["samples"])) < TOL
+        assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    assert np.all(np.isfinite(pdf.log_prob(want["samples"][:, -1])))
+
+
+@pytest.mark.parametrize("name", ["curve_d50_kappa800", "bingham_d50_vmax300", "curve_d200_kappa800"])
+def test_cooperative_fast_resume(gs, name):
+    """Cooperative fast kernels: a run split over launches equals the uninterrupted run to rounding (the a_i.x
+    recurrence is refreshed from x at launch start, so the split is visible at the 1e-13 level, never in the
+    integer outputs); DESIGN.md section 2 states the bitwise claim for the lane kernels and the exact mode only."""
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    x0 = gs.sample_sphere(d - 1, 96, seed=31)
+    ref = gs.ShrinkageSphericalSliceSampler(pdf, x0, 17, mode="fast", placement="packed")
+    ref.advance(150)
+    a = gs.ShrinkageSphericalSliceSampler(pdf, x0, 17, mode="fast", placement="packed")
+    for m in (37, 64, 1, 48):
+        a.advance(m)
+    assert np.max(np.abs(a.state - ref.state)) < 1e-11
+    assert np.array_equal(a.n_tries_per_chain, ref.n_tries_per_chain)
