@@ -4,11 +4,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsss_hip.so")
+LIB_PATH = os.environ.get("GSSS_HIP_LIB") or os.path.join(_HERE, "libgsss_hip.so")  # env: side-by-side A/B builds
 
 VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
 SHRINK, REJECT = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
+VARIANT_FAST_DOUBLE = 100
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
 ABI_VERSION = 4
 

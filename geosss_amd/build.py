@@ -20,6 +20,8 @@ ARCH = "gfx950"
 
 CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+# experiments: GSSS_HIPCC_FLAGS="-mllvm -foo" python -m geosss_amd.build --force
+CXXFLAGS += os.environ.get("GSSS_HIPCC_FLAGS", "").split()
 
 
 def hipcc():
@@ -54,7 +56,13 @@ def compile_one(src, force, extra):
     return obj, True
 
 
-def build(force=False, jobs=None, extra=(), verbose=True):
+def build(force=False, jobs=None, extra=(), verbose=True, out=None):
+    """`out`: write the library (and its objects) under another name -- side-by-side builds for A/B timing
+    (load one with GSSS_HIP_LIB=<path>)."""
+    global OBJ, LIB
+    if out:
+        LIB = os.path.abspath(out)
+        OBJ = os.path.join(CSRC, "_obj_" + os.path.splitext(os.path.basename(LIB))[0])
     os.makedirs(OBJ, exist_ok=True)
     srcs = sources()
     jobs = jobs or min(len(srcs), os.cpu_count() or 1)
@@ -76,6 +84,7 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--resource-usage", action="store_true", help="print per-kernel VGPR/SGPR/LDS usage")
+    ap.add_argument("--out", default=None, help="library path for a side-by-side experimental build")
     a = ap.parse_args()
     extra = ["-Rpass-analysis=kernel-resource-usage"] if a.resource_usage else []
-    build(force=a.force or a.resource_usage, jobs=a.jobs, extra=extra)
+    build(force=a.force or a.resource_usage, jobs=a.jobs, extra=extra, out=a.out)

@@ -291,6 +291,7 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     if (select_vec(d, 0) < 0) return GSSS_E_UNSUPPORTED;  // before any parameter array is touched
     std::vector<double> blob;
     bool bingham_diagonal = false;
+    double scale = 0.0;
     switch (desc->kind) {
     case GSSS_VMF_MIXTURE:
         if (k < 1 || !desc->mu || !desc->logc) {
@@ -299,6 +300,11 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
         }
         blob.assign(desc->mu, desc->mu + (size_t)k * d);
         blob.insert(blob.end(), desc->logc, desc->logc + k);
+        for (int c = 0; c < k; ++c) {
+            double ss = 0.0;
+            for (int i = 0; i < d; ++i) ss += desc->mu[(size_t)c * d + i] * desc->mu[(size_t)c * d + i];
+            scale = std::fmax(scale, std::sqrt(ss));
+        }
         break;
     case GSSS_BINGHAM:
         if (!desc->A) {
@@ -374,6 +380,7 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     t->tb.k = desc->kind == GSSS_BINGHAM ? (bingham_diagonal ? 1 : 0) : k;  // Bingham: k flags a diagonal A
     t->tb.dpad = 0;
     t->tb.kappa = desc->kappa;
+    t->tb.scale = scale;
     *out = t;
     return GSSS_OK;
 }
@@ -445,6 +452,10 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("replay_stride must be >= 1");
         return GSSS_E_INVALID;
     }
+    if (a->mode == GSSS_MODE_FAST && a->variant != 0 && a->variant != GSSS_VARIANT_FAST_DOUBLE) {
+        set_error("fast mode takes variant 0 or GSSS_VARIANT_FAST_DOUBLE");
+        return GSSS_E_INVALID;
+    }
     const int vec = a->mode == GSSS_MODE_FAST ? 0 : select_vec(t->tb.d, a->variant);
     if (vec < 0) return vec;
     RunBlock rb;
@@ -470,6 +481,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         return GSSS_E_INVALID;
     }
     rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= 2048) ? 1 : 0;
+    rb.screen = (a->mode == GSSS_MODE_FAST && a->variant == GSSS_VARIANT_FAST_DOUBLE) ? 0 : 1;
     DeviceGuard guard(t->device);
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -538,7 +550,9 @@ const char *gsss_kernel_name(const gsss_target *t, int32_t mode, int32_t variant
     const bool spread = placement == 2;
     if (mode == GSSS_MODE_FAST) {
         FastProbe pr;
-        if (fast_dispatch(t->tb, RunBlock{}, false, &pr, nullptr) != GSSS_OK) return name;
+        RunBlock rbp{};
+        rbp.screen = variant == GSSS_VARIANT_FAST_DOUBLE || spread ? 0 : 1;
+        if (fast_dispatch(t->tb, rbp, false, &pr, nullptr) != GSSS_OK) return name;
         if (pr.lane && spread && t->tb.d <= 16)
             snprintf(name, sizeof(name), "wave_kernel%s", strchr(pr.name, '<') ? strchr(pr.name, '<') : "");
         else

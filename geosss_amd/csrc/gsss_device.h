@@ -26,6 +26,8 @@ struct TargetBlock {
     const double *blob;  // device parameter blob, layout per kind (see gsss_capi.hip: build_blob)
     int32_t kind, d, k, dpad;
     double kappa;
+    double scale;  // largest magnitude the log-density varies by along a circle (vMF: max kappa; Bingham: spectral spread;
+                   // curve: kappa): the single-precision screen of the fast kernels is used while its error margin stays small
 };
 
 struct RunBlock {
@@ -42,6 +44,7 @@ struct RunBlock {
     int32_t sampler, max_tries;
     int64_t keep_rows;  // > 0: samples are written chain-major [chain][keep_rows][d]; 0: [row][d][chain]
     int32_t spread;     // lane layouts: one chain per WAVEFRONT (small ensembles: no divergence between chains)
+    int32_t screen;     // fast mode: tries are screened in single precision where the target's kernel is built for it
 };
 
 // address of component j of retained row `row` of chain c
@@ -57,6 +60,13 @@ __device__ __forceinline__ size_t sample_index(const RunBlock &a, int64_t row, i
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&o)[4])
 {
+    // The key is wave-uniform.  Left alone, the compiler hoists the ten round keys k + r W out of the sampler's
+    // loops as 20 long-lived scalar registers and then spills them into vector lanes (v_readlane on the vector
+    // pipe per use).  The empty asm makes the key opaque here, so the round keys are re-derived by ten
+    // scalar adds per call -- on the scalar unit, beside the vector work of the other wavefronts.
+    k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);  // (a no-op when the key already sits in a scalar register)
+    k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k1);
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;

@@ -1,5 +1,5 @@
 // GSSS_MODE_FAST instantiations for curve-vMF targets (10 knots, the reference's brownian_curve default).
-#include "gsss_fast.h"
+#include "gsss_spec64.h"
 
 namespace gsss {
 
@@ -15,7 +15,12 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, Fa
     }
     GSSS_FAST_CURVE_DIMS(GSSS_CASE)
 #undef GSSS_CASE
-    // larger d: lanes cooperate on one chain
+    // 64 < d <= 256, up to 17 knots: one chain per wavefront, four speculative tries per iteration
+    if (tb.d > 64 && tb.d <= 256 && tb.k >= 2 && tb.k <= 17) {
+        if (probe) GSSS_PROBE(false, "curve64_kernel<%d>", tb.k <= 11 ? 12 : 20);
+        return tb.k <= 11 ? do_curve64<12>(tb, rb, replay, st) : do_curve64<20>(tb, rb, replay, st);
+    }
+    // other large d: lanes cooperate on one chain
     if (tb.k == 10 && tb.d > 24 && tb.d <= 512) {
         if (probe)
             GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopCurve<10>>", tb.d <= 64 ? 16 : 64, tb.d <= 256 ? 4 : 8);

@@ -18,16 +18,56 @@
 namespace gsss {
 namespace fm {
 
+// A double constant for the addend slot of an FMA.  On the device it is materialised in a scalar register
+// pair by two s_mov_b32 right where it is used: scalar instructions issue beside the other wavefronts' vector
+// work, whereas hipcc, left alone, builds a single-use 64-bit addend in VECTOR registers (two v_mov_b32 in
+// front of every Horner step: +100 % vector issue on the polynomial) or hoists it out of the loop into a
+// long-lived register (the sampler loops then spill scalar registers into vector lanes).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <uint64_t BITS>
+__device__ __forceinline__ double kc()
+{
+    int lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((int)(uint32_t)(BITS & 0xffffffffull)));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((int)(uint32_t)(BITS >> 32)));
+    return __hiloint2double(hi, lo);
+}
+#else
+template <uint64_t BITS>
+inline double kc()
+{
+    double d;
+    const uint64_t b = BITS;
+    __builtin_memcpy(&d, &b, sizeof(d));
+    return d;
+}
+#endif
+
+#define GSSS_KC(x) ::gsss::fm::kc<__builtin_bit_cast(uint64_t, (double)(x))>()
+
+// a * b + k with the constant k read straight from its scalar register pair (one VOP3 instruction)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_k(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#else
+inline double fma_k(double a, double b, double k) { return fma(a, b, k); }
+#endif
+#define GSSS_FMAK(a, b, k) ::gsss::fm::fma_k((a), (b), GSSS_KC(k))
+
 // sin / cos kernels on |r| <= pi/4 (classic fdlibm minimax polynomials, |err| < 2^-57)
 GSSS_HD double sin_kernel(double r)
 {
     const double z = r * r;
     double p = 1.58969099521155010221e-10;
-    p = fma(p, z, -2.50507602534068634195e-08);
-    p = fma(p, z, 2.75573137070700676789e-06);
-    p = fma(p, z, -1.98412698298579493134e-04);
-    p = fma(p, z, 8.33333333332248946124e-03);
-    p = fma(p, z, -1.66666666666666324348e-01);
+    p = GSSS_FMAK(p, z, -2.50507602534068634195e-08);
+    p = GSSS_FMAK(p, z, 2.75573137070700676789e-06);
+    p = GSSS_FMAK(p, z, -1.98412698298579493134e-04);
+    p = GSSS_FMAK(p, z, 8.33333333332248946124e-03);
+    p = GSSS_FMAK(p, z, -1.66666666666666324348e-01);
     return fma(r * z, p, r);
 }
 
@@ -35,11 +75,11 @@ GSSS_HD double cos_kernel(double r)
 {
     const double z = r * r;
     double p = -1.13596475577881948265e-11;
-    p = fma(p, z, 2.08757232129817482790e-09);
-    p = fma(p, z, -2.75573143513906633035e-07);
-    p = fma(p, z, 2.48015872894767294178e-05);
-    p = fma(p, z, -1.38888888888741095749e-03);
-    p = fma(p, z, 4.16666666666666019037e-02);
+    p = GSSS_FMAK(p, z, 2.08757232129817482790e-09);
+    p = GSSS_FMAK(p, z, -2.75573143513906633035e-07);
+    p = GSSS_FMAK(p, z, 2.48015872894767294178e-05);
+    p = GSSS_FMAK(p, z, -1.38888888888741095749e-03);
+    p = GSSS_FMAK(p, z, 4.16666666666666019037e-02);
     // 1 - z/2 + z^2 p, with the 1 - z/2 rounding error folded back in
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
@@ -137,9 +177,9 @@ GSSS_HD double log_fast(double x)
     const double s = f / (2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double t1 = w * GSSS_FMAK(w, GSSS_FMAK(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * GSSS_FMAK(w, GSSS_FMAK(w, GSSS_FMAK(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                 2.857142874366239149e-01), 6.666666666666735130e-01);
     const double R = t1 + t2;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;

@@ -1,0 +1,511 @@
+// gsss_screen.h -- the lane-per-chain throughput kernel with single-precision SCREENING of the tries.
+//
+// A try of the shrinkage loop only needs a yes/no: is the level of y(theta) above the threshold
+// (mcmc.py:397)?  Four out of five tries are rejections, most of them by a wide margin.  So a try is
+// first evaluated in single precision on the hardware transcendentals (v_sin_f32 / v_cos_f32 / v_exp_f32:
+// 8 cycles each, against ~150 cycles for a double-precision sincos and ~75 per exp) together with a
+// RIGOROUS bound on the error of that evaluation:
+//
+//     level32 < threshold (1 - margin)   ->  rejected, exactly as the double-precision test would
+//     level32 > threshold (1 + margin)   ->  accepted, ditto
+//     otherwise                          ->  undecided: the double-precision level decides
+//
+// The margin is derived per step from the magnitudes of the step's coefficients and from the measured
+// worst-case errors of the hardware functions (tools/microbench/f32_trans_error.hip sweeps EVERY float of the
+// argument ranges used here: |sin|,|cos| error <= 1.254e-7, 2^x relative error <= 8.5e-8, log2 <= 6e-8).
+// Every decision is therefore the decision the all-double kernel (fast_kernel, gsss_fast.h) takes, and
+// everything that enters the chain -- theta, sin/cos of the accepted theta, the new state, the level
+// carried to the next step -- is computed in double precision exactly as there: the two kernels produce
+// the same chains bit for bit (tests/test_hip_parity.py::test_screened_equals_double).
+//
+// The double-precision work of an accepted (or undecided) try is DEFERRED to the next batched set-up
+// phase, where most lanes take part, instead of being executed for the few lanes that accepted in this
+// very iteration.  Scheduling (two chains per lane, one parked in LDS, set-up when enough lanes wait) is
+// that of fast_kernel.
+#pragma once
+#include "gsss_fast.h"
+
+namespace gsss {
+
+enum : int32_t { kFinalAccept = 3, kFinalDecide = 4 };  // try stopped at theta = aux: accepted for sure / double precision decides
+
+// |v_cos_f32(fl32(theta / 2 pi)) - cos(theta)| for |theta| <= 2 pi: 1.254e-7 from the hardware (exhaustive sweep)
+// + 2 pi 2^-25 from rounding the argument (in revolutions, |t| <= 1) to single precision; same for sin
+constexpr float kSinCosErr32 = 3.5e-7f;
+constexpr float kUnit32 = 5.9604645e-8f;  // 2^-24
+constexpr float kExp2Err32 = 8.5e-8f;     // relative error of v_exp_f32 on normal results (exhaustive sweep)
+constexpr float kLog2Err32 = 1.3e-7f;     // log2 of a double via frexp + v_log_f32 of the mantissa rounded to single
+
+__device__ __forceinline__ void sincos_rev32(double theta, float &s, float &c)
+{
+    const float t = (float)(theta * 0.15915494309189535);  // revolutions
+    s = __builtin_amdgcn_sinf(t);
+    c = __builtin_amdgcn_cosf(t);
+}
+
+// log2 of a positive finite double to single precision
+__device__ __forceinline__ float log2_32(double v)
+{
+    int e;
+    const double m = frexp(v, &e);
+    return (float)e + __builtin_amdgcn_logf((float)m);
+}
+
+// ------------------------------------------------------------------------------------------
+// screening side of the restricted targets.  A target provides, next to gsss_fast.h's interface,
+//   Keep / kKeepWords      double-precision values that persist from step to step
+//   kCoef32Floats          size of the single-precision pack q[]
+//   coeffs(cf, x, u)       the double-precision coefficients again (bit-identical to make()'s)
+//   make32(cf, keep, thr, q)   single-precision pack + error margin for the step
+//   screen(q, c, s)        -1 reject / +1 accept (both certain) / 0 undecided
+//   level_exact(cf, keep, c, s)   the double-precision level fast_kernel compares with thr
+//   kCarry                 the accepted point's level is the next step's level of x
+// ------------------------------------------------------------------------------------------
+template <int D, int KC>
+struct ScreenVmf : FastVmf<D, KC> {
+    using Base = FastVmf<D, KC>;
+    using Coef = typename Base::Coef;
+    static constexpr int kKeepWords = 1;  // m, the offset of the exponents
+    static constexpr int kCoef32Floats = 3 * KC + 1;
+    static constexpr bool kCarry = !Base::kScreened;
+
+    __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
+    {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            double ax = 0.0, au = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double mkj = this->mu[k * D + j];
+                ax = fma(mkj, x[j], ax);
+                au = fma(mkj, u[j], au);
+            }
+            cf.ax[k] = ax;
+            cf.au[k] = au;
+        }
+    }
+    // exponents to base 2, relative to log2(thr): q = [ax L | au L | (logc - m) L - log2 thr | margin]
+    __device__ __forceinline__ void make32(const Coef &cf, double thr, float (&q)[kCoef32Floats]) const
+    {
+        constexpr double L = 1.4426950408889634074;
+        const float t2 = log2_32(thr);
+        float b = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            q[k] = (float)(cf.ax[k] * L);
+            q[KC + k] = (float)(cf.au[k] * L);
+            q[2 * KC + k] = (float)((this->logc[k] - cf.m) * L - (double)t2);
+            b = fmaxf(b, fabsf(q[k]) + fabsf(q[KC + k]) + fabsf(q[2 * KC + k]));
+        }
+        // error of one exponent: (|ax| + |au|) (eps_sincos + 2^-24) + |lc| 2^-24 + two fma roundings + log2(thr)
+        const float e_a = b * (kSinCosErr32 + 3.0f * kUnit32) + kLog2Err32;
+        // relative error of the sum of 2^exponent: ln 2 * e_a (1 + e_a) + v_exp_f32 + the additions; 25 % on top
+        float margin = 1.25f * (0.69315f * e_a * (1.0f + e_a) + kExp2Err32 + (float)KC * kUnit32) + 1.0e-7f;
+        if (!(thr > 1e-290 && thr < 1e290) || !(margin < 0.25f)) margin = INFINITY;  // (also thr = 0, NaN): always double
+        q[3 * KC] = margin;
+    }
+    __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const
+    {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) sum += __builtin_amdgcn_exp2f(fmaf(c, q[k], fmaf(s, q[KC + k], q[2 * KC + k])));
+        const float margin = q[3 * KC];
+        return sum < 1.0f - margin ? -1 : (sum > 1.0f + margin ? 1 : 0);
+    }
+    __device__ __forceinline__ double level_exact(const Coef &cf, double c, double s) const
+    {
+        double a[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) a[k] = fma(c, cf.ax[k], fma(s, cf.au[k], this->logc[k])) - cf.m;
+        return this->level_full(a);
+    }
+    __device__ __forceinline__ double keep_get(const Coef &cf) const { return cf.m; }
+    __device__ __forceinline__ void keep_set(Coef &cf, double v) const { cf.m = v; }
+};
+
+template <int D, class TP>
+struct ScreenChain {
+    static constexpr int kQ = TP::kCoef32Floats + (TP::kCoef32Floats & 1);  // padded to whole 64-bit words
+    double x[D], u[D];
+    double lo, hi, thr;
+    double aux;   // kPending: level of x carried from the accepting try; kFinal*: theta of the stopped try
+    double keep;  // TP's persistent double (vMF: m)
+    float q[kQ];
+    uint32_t n_try;
+    int32_t steps_done, row, t, status, err, cursor;
+    static constexpr int kWordsNoReplay = 2 * D + 4 + TP::kKeepWords + kQ / 2 + 2;
+    static constexpr int kWords = kWordsNoReplay + 1;
+};
+
+template <int D, class TP>
+__host__ __device__ constexpr bool screen_parks()
+{
+    return (size_t)ScreenChain<D, TP>::kWords * kBlock * sizeof(double) <= 72 * 1024;
+}
+template <int D, class TP, bool REPLAY>
+__host__ __device__ constexpr size_t screen_lds_doubles()
+{
+    return TP::lds_doubles() + (screen_parks<D, TP>() ? (size_t)(REPLAY ? ScreenChain<D, TP>::kWords
+                                                                        : ScreenChain<D, TP>::kWordsNoReplay) * kBlock
+                                                      : 0);
+}
+
+__device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long *slot)
+{
+    const unsigned long long mine = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    const unsigned long long o = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    a = __uint_as_float((uint32_t)o);
+    b = __uint_as_float((uint32_t)(o >> 32));
+}
+
+template <int D, class TP, bool REPLAY>
+__global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlock a)
+{
+    using V = LaneVec<D>;
+    using Chain = ScreenChain<D, TP>;
+    using Coef = typename TP::Coef;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    TP tp;
+    tp.stage(lds, tb);
+    unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles()) + threadIdx.x;
+    __syncthreads();
+
+    const int32_t n = (int32_t)a.n_chains;
+    const int32_t n_steps = (int32_t)a.n_steps;
+    const bool shrink = a.sampler == GSSS_SHRINK;
+    const int32_t thin = (int32_t)a.thin;
+    const int32_t max_tries = a.max_tries < (1 << 25) ? a.max_tries : (1 << 25) - 1;  // t shares a word with the flags
+    constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
+    constexpr bool kPark = screen_parks<D, TP>();
+    constexpr int kPerBlock = kPark ? 2 * kBlock : kBlock;
+    const int32_t id0 = (int32_t)blockIdx.x * kPerBlock + (int32_t)threadIdx.x;
+    const int32_t id1 = id0 + kBlock;
+
+    Chain cur;
+    int32_t slot = 0;
+    int32_t parked_status = kDone;
+
+    auto chain_id = [&]() { return slot ? id1 : id0; };
+    auto philox = [&]() {
+        PhiloxDraws<V> dr;
+        dr.init(a, chain_id(), D);
+        dr.begin_step(a.step_offset + (uint64_t)cur.steps_done);
+        return dr;
+    };
+    auto replay_take = [&]() -> double {
+        if (cur.cursor >= (int32_t)a.replay_stride) {
+            cur.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            return 0.5;
+        }
+        return a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor++];
+    };
+    auto count_tries = [&]() {
+        const uint32_t sum = cur.n_try + (uint32_t)cur.t;
+        if (sum < cur.n_try) cur.err |= GSSS_CHAIN_COUNTER_SATURATED;
+        cur.n_try = sum < cur.n_try ? 0xFFFFFFFFu : sum;
+    };
+    auto needs_service = [](int32_t st) { return st == kPending || st == kFinalAccept || st == kFinalDecide; };
+
+    auto init = [&]() {
+        const int32_t c = chain_id();
+        const bool valid = c < n;
+        const int32_t cc = valid ? c : 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cur.x[j] = a.state[(size_t)j * n + cc];
+#pragma unroll
+        for (int j = 0; j < D; ++j) cur.u[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < Chain::kQ; ++i) cur.q[i] = 0.0f;
+        cur.lo = cur.hi = cur.thr = cur.aux = cur.keep = 0.0;
+        cur.n_try = 0u;
+        cur.steps_done = 0;
+        cur.row = 0;
+        cur.err = 0;
+        cur.cursor = 0;
+        cur.t = 0;
+        cur.status = (valid && n_steps > 0) ? kPending : kDone;
+    };
+
+    // everything a step needs before its first try (mcmc.py:387-392); arithmetic identical to fast_kernel's
+    auto setup = [&]() {
+        double u_thr, u_th0;
+        if (REPLAY) {
+            if (cur.cursor + D <= (int32_t)a.replay_stride) {
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    cur.u[j] = a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor + j];
+                cur.cursor += D;
+            } else {
+#pragma unroll
+                for (int j = 0; j < D; ++j) cur.u[j] = 0.5;
+                cur.cursor = (int32_t)a.replay_stride;
+                cur.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            }
+            u_thr = replay_take();
+            u_th0 = shrink ? replay_take() : 0.0;
+        } else {
+            const PhiloxDraws<V> dr = philox();
+            dr.normals(cur.u, 0);
+            dr.block(0u, u_thr, u_th0);
+        }
+        {  // u = spherical_projection(z, x), sphere.py:29-33
+            const double rnx = inv_norm(vdot<V>(cur.x, cur.x));
+            double cz = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) cz = fma(cur.u[j], cur.x[j] * rnx, cz);
+#pragma unroll
+            for (int j = 0; j < D; ++j) cur.u[j] = fma(-cz, cur.x[j] * rnx, cur.u[j]);
+            const double rnw = inv_norm(vdot<V>(cur.u, cur.u));
+#pragma unroll
+            for (int j = 0; j < D; ++j) cur.u[j] *= rnw;
+        }
+        Coef cf;
+        tp.keep_set(cf, cur.keep);
+        const double lvl0 = tp.make(cf, cur.x, cur.u, cur.aux, cur.steps_done == 0);
+        cur.keep = tp.keep_get(cf);
+        bool finite;
+        if (TP::kLinear) {
+            cur.thr = lvl0 * u_thr;
+            finite = lvl0 > 0.0 && lvl0 < INFINITY;
+        } else {
+            cur.thr = lvl0 + fm::log_fast(u_thr);
+            finite = lvl0 > -INFINITY && lvl0 < INFINITY;
+        }
+        tp.make32(cf, cur.thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
+        if (shrink) {
+            cur.hi = kTwoPi * u_th0;
+            cur.lo = cur.hi - kTwoPi;
+        } else {
+            cur.lo = 0.0;
+            cur.hi = kTwoPi;
+        }
+        cur.t = 0;
+        cur.status = kReady;
+        if (!finite) {
+            cur.err |= GSSS_CHAIN_NONFINITE;
+            cur.status = kDone;
+        }
+    };
+
+    // up to two proposals, screened in single precision (one Philox block feeds a pair of tries: the first
+    // uniform of block j is try 2j, the second try 2j + 1)
+    auto attempt = [&]() {
+        if (cur.t >= max_tries) {
+            count_tries();
+            cur.err |= GSSS_CHAIN_MAX_TRIES;
+            cur.status = kDone;
+            return;
+        }
+        double u_pair[2];
+        if (!REPLAY) philox().block(kTryBase + (uint32_t)(cur.t >> 1), u_pair[0], u_pair[1]);
+        const int first = REPLAY ? 0 : (cur.t & 1);  // odd: the pair's first try was decided in double precision already
+        bool stopped = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!stopped && h >= first && (h == first || cur.t < max_tries) &&
+                !(REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
+                const double uu = REPLAY ? replay_take() : u_pair[h];
+                if (REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED)) {
+                    stopped = true;  // nothing left to propose with
+                } else {
+                    const double theta = fma(cur.hi - cur.lo, uu, cur.lo);  // mcmc.py:395
+                    ++cur.t;
+                    float s32, c32;
+                    sincos_rev32(theta, s32, c32);
+                    const int verdict = tp.screen(reinterpret_cast<const float (&)[TP::kCoef32Floats]>(cur.q), c32, s32);
+                    if (verdict < 0) {
+                        if (shrink) {  // mcmc.py:400
+                            if (theta < 0.0)
+                                cur.lo = theta;
+                            else
+                                cur.hi = theta;
+                        }
+                    } else {
+                        cur.aux = theta;
+                        cur.status = verdict > 0 ? kFinalAccept : kFinalDecide;
+                        stopped = true;
+                    }
+                }
+            }
+        }
+        if (REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED) && cur.status == kReady) {
+            count_tries();
+            cur.status = kDone;
+        }
+    };
+
+    // the double-precision part of a stopped try: decide it if the screen could not, then move (mcmc.py:396-399)
+    auto finalise = [&]() {
+        const double theta = cur.aux;
+        double sn, cs;
+        fm::sincos_small(theta, sn, cs);
+        bool accepted = true;
+        double lvl = 0.0;
+        if (TP::kCarry || cur.status == kFinalDecide) {
+            Coef cf;
+            tp.coeffs(cf, cur.x, cur.u);
+            tp.keep_set(cf, cur.keep);
+            lvl = tp.level_exact(cf, cs, sn);
+            if (cur.status == kFinalDecide) accepted = lvl > cur.thr;  // mcmc.py:397
+        }
+        if (accepted) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
+            cur.aux = lvl;
+            count_tries();
+            ++cur.steps_done;
+            if (a.samples != nullptr && cur.steps_done == (cur.row + 1) * thin) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                ++cur.row;
+            }
+            const bool exhausted = REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
+            cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
+        } else {
+            if (shrink) {  // mcmc.py:400
+                if (theta < 0.0)
+                    cur.lo = theta;
+                else
+                    cur.hi = theta;
+            }
+            cur.status = kReady;
+        }
+    };
+
+    auto pack_flags = [&]() { return cur.t | (cur.status << 25) | (int32_t)((uint32_t)cur.err << 28); };
+    auto trade = [&]() {
+        unsigned long long *p = park;
+        auto word = [&](double &v) {
+            lds_trade(v, p);
+            p += kBlock;
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) word(cur.x[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) word(cur.u[j]);
+        word(cur.lo);
+        word(cur.hi);
+        word(cur.thr);
+        word(cur.aux);
+        if (TP::kKeepWords) word(cur.keep);
+#pragma unroll
+        for (int i = 0; i < Chain::kQ; i += 2) {
+            lds_trade(cur.q[i], cur.q[i + 1], p);
+            p += kBlock;
+        }
+        lds_trade(cur.steps_done, cur.row, p);
+        p += kBlock;
+        if (REPLAY) {
+            int32_t zero = 0;
+            lds_trade(cur.cursor, zero, p);
+            p += kBlock;
+        }
+        const int32_t st = cur.status;
+        int32_t nt = (int32_t)cur.n_try, packed = pack_flags();
+        lds_trade(nt, packed, p);
+        cur.n_try = (uint32_t)nt;
+        cur.t = packed & 0x1FFFFFF;
+        cur.status = (packed >> 25) & 7;
+        cur.err = (int32_t)((uint32_t)packed >> 28);
+        parked_status = st;
+        slot ^= 1;
+    };
+
+    auto flush = [&]() {
+        const int32_t c = chain_id();
+        if (c >= n) return;
+#pragma unroll
+        for (int j = 0; j < D; ++j) a.state[(size_t)j * n + c] = cur.x[j];
+        if (a.n_reject) a.n_reject[c] += (int64_t)cur.n_try - cur.steps_done;
+        if (a.n_tries) a.n_tries[c] += (int64_t)cur.n_try;
+        if (a.err && cur.err) a.err[c] |= cur.err;
+    };
+
+    if (kPark) {  // the chain of slot 1 is initialised, set up and parked; then the chain of slot 0
+        slot = 1;
+        init();
+        if (cur.status == kPending) setup();
+        unsigned long long *p = park;
+        auto put = [&](double v) {
+            *p = (unsigned long long)__double_as_longlong(v);
+            p += kBlock;
+        };
+        auto put2 = [&](uint32_t lo32, uint32_t hi32) {
+            *p = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
+            p += kBlock;
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) put(cur.x[j]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) put(cur.u[j]);
+        put(cur.lo);
+        put(cur.hi);
+        put(cur.thr);
+        put(cur.aux);
+        if (TP::kKeepWords) put(cur.keep);
+#pragma unroll
+        for (int i = 0; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
+        put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
+        if (REPLAY) put2((uint32_t)cur.cursor, 0u);
+        put2(cur.n_try, (uint32_t)pack_flags());
+        parked_status = cur.status;
+    }
+    slot = 0;
+    init();
+    if (cur.status == kPending) setup();
+
+    bool stuck = false;
+    for (;;) {
+        // a lane whose current chain cannot try (stopped, waiting or finished) takes its other chain when that one can
+        if (kPark && cur.status != kReady && parked_status == kReady) trade();
+        const unsigned long long trying = __ballot(cur.status == kReady);
+        if (cur.status == kReady) attempt();
+        const unsigned long long live = __ballot(cur.status != kDone || parked_status != kDone);
+        if (live == 0ull) break;
+        const unsigned long long waiting = __ballot(needs_service(cur.status));  // nothing to try until serviced
+        const unsigned long long pend = __ballot(needs_service(cur.status) || needs_service(parked_status));
+        const int n_live = __popcll(live);
+        const bool service = pend != 0ull && (2 * __popcll(waiting) >= n_live || 8 * __popcll(pend) >= 7 * n_live);
+        if (service) {
+            if (kPark && !needs_service(cur.status) && needs_service(parked_status)) trade();  // bring the waiting chain in
+            if (cur.status == kFinalAccept || cur.status == kFinalDecide) finalise();
+            if (cur.status == kPending) setup();
+        }
+        if (trying == 0ull && !service && __ballot(kPark && cur.status != kReady && parked_status == kReady) == 0ull) {
+            stuck = true;  // no lane tried, nothing was serviced, nothing to trade in: cannot happen; never spin on the GPU
+            break;
+        }
+    }
+    if (stuck && cur.status != kDone) cur.err |= GSSS_CHAIN_MAX_TRIES | GSSS_CHAIN_COUNTER_SATURATED;
+    flush();
+    if (kPark) {
+        trade();
+        flush();
+    }
+}
+
+template <int D, class TP, bool REPLAY>
+int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
+{
+    const size_t lds = screen_lds_doubles<D, TP, REPLAY>() * sizeof(double);
+    auto kern = screened_kernel<D, TP, REPLAY>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GSSS_E_HIP;
+        }
+    }
+    const int per_block = screen_parks<D, TP>() ? 2 * kBlock : kBlock;
+    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("screened kernel launch failed: %s", hipGetErrorString(e));
+        return GSSS_E_HIP;
+    }
+    return GSSS_OK;
+}
+
+}  // namespace gsss

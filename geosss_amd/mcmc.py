@@ -91,7 +91,7 @@ class RejectionSphericalSliceSampler:
     _sampler = _lib.REJECT
 
     def __init__(self, distribution, initial_state, seed=None, *, device=None, mode="auto", max_tries=None,
-                 chain_offset=0, step_offset=0, variant=0, rng="philox", placement="auto"):
+                 chain_offset=0, step_offset=0, variant=0, rng="philox", placement="auto", screen=True):
         if rng not in ("philox", "numpy"):
             raise ValueError("rng must be 'philox' or 'numpy'")
         if placement not in ("auto", "packed", "spread"):
@@ -117,6 +117,7 @@ class RejectionSphericalSliceSampler:
         self.max_tries = int(max_tries) if max_tries is not None else (1 << 20)
         self.chain_offset = int(chain_offset)
         self.variant = int(variant)
+        self.screen = bool(screen)  # fast mode: single-precision screening of the tries (same chains); False = all-double kernels
         self._step = int(step_offset)
         self._target_dev = distribution._device_target(self.device)
         self._set_state(initial_state)
@@ -309,7 +310,7 @@ class RejectionSphericalSliceSampler:
         a.sampler = self._sampler
         a.mode = _MODES[self.mode]
         a.max_tries = min(self.max_tries, 2**31 - 1)
-        a.variant = self.variant
+        a.variant = self.variant if self.mode != "fast" else (0 if self.screen else _lib.VARIANT_FAST_DOUBLE)
         if self._rng_state is not None:
             if replay is not None:
                 raise ValueError("replay and rng='numpy' are mutually exclusive")

@@ -47,6 +47,10 @@ extern "C" {
 #define GSSS_MODE_EXACT 0 /* y = cos*x + sin*u formed, log_prob(y) evaluated from y op by op as the reference does */
 #define GSSS_MODE_FAST 1  /* log_prob restricted to the great circle: O(1) per try after O(d) per step (same value to ~1e-14) */
 
+/* gsss_run_args.variant in GSSS_MODE_FAST: 0 = library's choice (tries screened in single precision with a rigorous error
+ * margin, double precision where the margin does not decide: same chains); this value forces the all-double kernels */
+#define GSSS_VARIANT_FAST_DOUBLE 100
+
 /* return codes */
 #define GSSS_OK 0
 #define GSSS_E_INVALID (-1)     /* bad argument */

@@ -594,3 +594,37 @@ def test_cooperative_fast_resume(gs, name):
         a.advance(m)
     assert np.max(np.abs(a.state - ref.state)) < 1e-11
     assert np.array_equal(a.n_tries_per_chain, ref.n_tries_per_chain)
+
+
+SCREEN_CASES = [("vmfmix_readme", 200_000, 60), ("vmfmix_k10_kappa500", 100_000, 40), ("vmfmix_d10_k5_kappa100", 50_000, 40),
+                ("vmfmix_d4_k4_weighted", 50_000, 40)]
+
+
+@pytest.mark.parametrize("name,n_chains,n_steps", SCREEN_CASES)
+@pytest.mark.parametrize("sampler", ["shrink", "reject"])
+def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
+    """The single-precision screen only ever takes decisions its error margin guarantees, everything else is
+    decided and computed in double precision: the screened kernel and the all-double kernel give the SAME chains
+    -- states bit for bit, tries and rejections exactly -- over ~10^8 proposals."""
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=77).T
+    cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    if sampler == "reject":
+        n_chains, n_steps = n_chains // 10, n_steps // 2
+        x0 = x0[:n_chains]
+    out = {}
+    for screen in (True, False):
+        s = cls(pdf, x0, seed=5, mode="fast", placement="packed", screen=screen)
+        name_k = s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0 if screen else 100, 1).decode()
+        assert name_k.startswith("screened_kernel" if screen else "fast_kernel"), name_k
+        s.advance(n_steps // 2)
+        s.advance(n_steps - n_steps // 2)          # the split exercises the per-launch state hand-over
+        assert int((s._err != 0).sum().item()) == 0
+        out[screen] = (s.state_device.clone(), s._n_tries.clone(), s._n_reject.clone())
+    import torch
+    assert torch.equal(out[True][1], out[False][1])
+    assert torch.equal(out[True][2], out[False][2])
+    assert torch.equal(out[True][0], out[False][0])
+    assert int(out[True][1].sum().item()) > 4 * n_chains * n_steps * (0.9 if sampler == "shrink" else 1.0)
