@@ -90,17 +90,16 @@ struct FastVmf {
             cf.ax[k] = ax;
             cf.au[k] = au;
         }
-        // the offset m only keeps the exponentials in range; re-centre it when the carried level
-        // has drifted far from 1 (or on the first step of a launch)
-        if (kScreened || fresh || !(lvl > 1e-150 && lvl < 1e150)) {
-            double m = -INFINITY;
+        // level of x itself, computed from x as the reference does for its threshold (mcmc.py:389); the offset m
+        // only keeps the exponentials in range
+        (void)fresh;
+        double m = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + logc[k]);
-            cf.m = m;
-            lvl = 0.0;
+        for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + logc[k]);
+        cf.m = m;
+        lvl = 0.0;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) lvl += fm::exp_fast((cf.ax[k] + logc[k]) - m);
-        }
+        for (int k = 0; k < KC; ++k) lvl += fm::exp_fast((cf.ax[k] + logc[k]) - m);
         return lvl;
     }
     // Many components: only the largest term is exponentiated in double; the others are bounded from
@@ -853,15 +852,14 @@ struct CoopVmf {
     }
     __device__ __forceinline__ double level0(typename Scalar::Coef &cf, double carried, bool fresh) const
     {
-        if (Scalar::kScreened || fresh || !(carried > 1e-150 && carried < 1e150)) {
-            double m = -INFINITY;
+        (void)fresh;
+        double m = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + sc.logc[k]);
-            cf.m = m;
-            carried = 0.0;
+        for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + sc.logc[k]);
+        cf.m = m;
+        carried = 0.0;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) carried += fm::exp_fast((cf.ax[k] + sc.logc[k]) - m);
-        }
+        for (int k = 0; k < KC; ++k) carried += fm::exp_fast((cf.ax[k] + sc.logc[k]) - m);
         return carried;
     }
 };

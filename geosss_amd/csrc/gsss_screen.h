@@ -65,9 +65,9 @@ template <int D, int KC>
 struct ScreenVmf : FastVmf<D, KC> {
     using Base = FastVmf<D, KC>;
     using Coef = typename Base::Coef;
-    static constexpr int kKeepWords = 1;  // m, the offset of the exponents
+    static constexpr int kKeepWords = 0;
     static constexpr int kCoef32Floats = 3 * KC + 1;
-    static constexpr bool kCarry = !Base::kScreened;
+    static constexpr bool kCarry = false;  // the level of x is formed from x at set-up (make), as the reference does
 
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
@@ -83,26 +83,49 @@ struct ScreenVmf : FastVmf<D, KC> {
             cf.ax[k] = ax;
             cf.au[k] = au;
         }
+        double m = -INFINITY;  // the offset make() chose for this step
+#pragma unroll
+        for (int k = 0; k < KC; ++k) m = fmax(m, cf.ax[k] + this->logc[k]);
+        cf.m = m;
     }
-    // exponents to base 2, relative to log2(thr): q = [ax L | au L | (logc - m) L - log2 thr | margin]
-    __device__ __forceinline__ void make32(const Coef &cf, double thr, float (&q)[kCoef32Floats]) const
+    // Exponents to base 2, relative to log2 of the threshold thr = level(x) U (mcmc.py:389):
+    //   q = [ax L | au L | (logc - m) L - log2 thr | margin].
+    // log2 thr itself is only formed in single precision here (its error is part of the margin); the double-
+    // precision threshold is formed when a try is left undecided (threshold()).  Returns false when the level of
+    // x is not a positive finite number.
+    __device__ __forceinline__ bool make32(const Coef &cf, double u_thr, float (&q)[kCoef32Floats]) const
     {
         constexpr double L = 1.4426950408889634074;
-        const float t2 = log2_32(thr);
-        float b = 0.0f;
+        float b = 0.0f, s0 = 0.0f;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             q[k] = (float)(cf.ax[k] * L);
             q[KC + k] = (float)(cf.au[k] * L);
-            q[2 * KC + k] = (float)((this->logc[k] - cf.m) * L - (double)t2);
-            b = fmaxf(b, fabsf(q[k]) + fabsf(q[KC + k]) + fabsf(q[2 * KC + k]));
+            q[2 * KC + k] = (float)((this->logc[k] - cf.m) * L);
+            s0 += __builtin_amdgcn_exp2f(q[k] + q[2 * KC + k]);  // theta = 0: cos = 1, sin = 0 exactly
         }
-        // error of one exponent: (|ax| + |au|) (eps_sincos + 2^-24) + |lc| 2^-24 + two fma roundings + log2(thr)
-        const float e_a = b * (kSinCosErr32 + 3.0f * kUnit32) + kLog2Err32;
+        // log2(level(x) U): s0 lies in [1, K] (the largest exponent is 0 up to rounding)
+        int e;
+        const float m0 = frexpf(s0, &e);
+        const float t2 = ((float)e + __builtin_amdgcn_logf(m0)) + log2_32(u_thr);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            q[2 * KC + k] -= t2;
+            b = fmaxf(b, fabsf(q[k]) + fabsf(q[KC + k]) + fabsf(q[2 * KC + k]) + fabsf(t2));
+        }
+        // error of one exponent of a try: (|ax| + |au|) (eps_sincos + 2^-24) + |lc| 2^-24 + two fma roundings, plus the
+        // error of log2 thr: three roundings per exponent of s0, v_exp_f32, the additions, v_log_f32 twice, the subtraction
+        const float e_a = b * (kSinCosErr32 + 7.0f * kUnit32) + (1.4427f * (kExp2Err32 + (float)KC * kUnit32) + 6.0e-8f + kLog2Err32);
         // relative error of the sum of 2^exponent: ln 2 * e_a (1 + e_a) + v_exp_f32 + the additions; 25 % on top
         float margin = 1.25f * (0.69315f * e_a * (1.0f + e_a) + kExp2Err32 + (float)KC * kUnit32) + 1.0e-7f;
-        if (!(thr > 1e-290 && thr < 1e290) || !(margin < 0.25f)) margin = INFINITY;  // (also thr = 0, NaN): always double
+        if (!(u_thr > 1e-290) || !(margin < 0.25f)) margin = INFINITY;  // (also U = 0, NaN): double precision decides every try
         q[3 * KC] = margin;
+        return s0 > 0.5f && s0 < 3.0e38f;
+    }
+    // the double-precision threshold of the step, exactly as fast_kernel forms it
+    __device__ __forceinline__ double threshold(Coef &cf, const double (&x)[D], const double (&u)[D], double u_thr) const
+    {
+        return this->make(cf, x, u, 0.0, true) * u_thr;
     }
     __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const
     {
@@ -119,17 +142,18 @@ struct ScreenVmf : FastVmf<D, KC> {
         for (int k = 0; k < KC; ++k) a[k] = fma(c, cf.ax[k], fma(s, cf.au[k], this->logc[k])) - cf.m;
         return this->level_full(a);
     }
-    __device__ __forceinline__ double keep_get(const Coef &cf) const { return cf.m; }
-    __device__ __forceinline__ void keep_set(Coef &cf, double v) const { cf.m = v; }
+    __device__ __forceinline__ double keep_get(const Coef &) const { return 0.0; }
+    __device__ __forceinline__ void keep_set(Coef &, double) const {}
 };
 
 template <int D, class TP>
 struct ScreenChain {
     static constexpr int kQ = TP::kCoef32Floats + (TP::kCoef32Floats & 1);  // padded to whole 64-bit words
     double x[D], u[D];
-    double lo, hi, thr;
-    double aux;   // kPending: level of x carried from the accepting try; kFinal*: theta of the stopped try
-    double keep;  // TP's persistent double (vMF: m)
+    double lo, hi;
+    double thr;   // the step's uniform U of the threshold (mcmc.py:389); the threshold itself is formed on demand
+    double aux;   // kFinal*: theta of the stopped try
+    double keep;  // a target's persistent double, if it has one
     float q[kQ];
     uint32_t n_try;
     int32_t steps_done, row, t, status, err, cursor;
@@ -260,18 +284,9 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
             for (int j = 0; j < D; ++j) cur.u[j] *= rnw;
         }
         Coef cf;
-        tp.keep_set(cf, cur.keep);
-        const double lvl0 = tp.make(cf, cur.x, cur.u, cur.aux, cur.steps_done == 0);
-        cur.keep = tp.keep_get(cf);
-        bool finite;
-        if (TP::kLinear) {
-            cur.thr = lvl0 * u_thr;
-            finite = lvl0 > 0.0 && lvl0 < INFINITY;
-        } else {
-            cur.thr = lvl0 + fm::log_fast(u_thr);
-            finite = lvl0 > -INFINITY && lvl0 < INFINITY;
-        }
-        tp.make32(cf, cur.thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
+        tp.coeffs(cf, cur.x, cur.u);
+        cur.thr = u_thr;  // the uniform; the double-precision threshold is formed only if a try stays undecided
+        const bool finite = tp.make32(cf, u_thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
         if (shrink) {
             cur.hi = kTwoPi * u_th0;
             cur.lo = cur.hi - kTwoPi;
@@ -340,18 +355,14 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         double sn, cs;
         fm::sincos_small(theta, sn, cs);
         bool accepted = true;
-        double lvl = 0.0;
-        if (TP::kCarry || cur.status == kFinalDecide) {
+        if (cur.status == kFinalDecide) {  // rare: the double-precision test itself (mcmc.py:389, 397)
             Coef cf;
-            tp.coeffs(cf, cur.x, cur.u);
-            tp.keep_set(cf, cur.keep);
-            lvl = tp.level_exact(cf, cs, sn);
-            if (cur.status == kFinalDecide) accepted = lvl > cur.thr;  // mcmc.py:397
+            const double thr = tp.threshold(cf, cur.x, cur.u, cur.thr);
+            accepted = tp.level_exact(cf, cs, sn) > thr;
         }
         if (accepted) {
 #pragma unroll
             for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
-            cur.aux = lvl;
             count_tries();
             ++cur.steps_done;
             if (a.samples != nullptr && cur.steps_done == (cur.row + 1) * thin) {
@@ -465,7 +476,9 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         const unsigned long long waiting = __ballot(needs_service(cur.status));  // nothing to try until serviced
         const unsigned long long pend = __ballot(needs_service(cur.status) || needs_service(parked_status));
         const int n_live = __popcll(live);
-        const bool service = pend != 0ull && (2 * __popcll(waiting) >= n_live || 8 * __popcll(pend) >= 7 * n_live);
+        // the service phase (double precision) costs several try iterations (single precision): it runs when three
+        // quarters of the live lanes wait for it (or seven eighths have something for it)
+        const bool service = pend != 0ull && (4 * __popcll(waiting) >= 3 * n_live || 8 * __popcll(pend) >= 7 * n_live);
         if (service) {
             if (kPark && !needs_service(cur.status) && needs_service(parked_status)) trade();  // bring the waiting chain in
             if (cur.status == kFinalAccept || cur.status == kFinalDecide) finalise();

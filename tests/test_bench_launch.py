@@ -15,7 +15,7 @@ from conftest import ROOT
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(args, env_extra=None, timeout=600):
+def _run(args, env_extra=None, timeout=240):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra or {})
     return subprocess.run([sys.executable, BENCH, *args], env=env, capture_output=True, text=True, timeout=timeout)

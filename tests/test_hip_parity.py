@@ -480,33 +480,57 @@ def test_long_chains_stay_on_the_oracle_trajectory(gs, oracle):
         assert np.max(np.abs(s.state - want["state"])) < TOL, (mode, placement)
 
 
+_RCCL_BODY = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import geosss_amd as gs
+from geosss_amd import ensemble
+from conftest import golden
+from helpers import product_target
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = {port!r}
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+try:
+    x = gs.sample_sphere_device(2, 1000, seed=1)
+    out = ensemble.gather_states(x, always_collective=True)
+    assert out.shape == x.shape and torch.equal(out, x)
+    out = ensemble.gather_states(x, always_collective=True, counts=[1000])
+    assert torch.equal(out, x)
+    t = torch.tensor([5, 7], dtype=torch.int64, device="cuda")
+    assert torch.equal(ensemble.reduce_sum(t.clone()), t)
+    dist.barrier()
+    assert ensemble.shard_bounds(1000) == (0, 1000)
+    s = ensemble.sharded_sampler(gs.ShrinkageSphericalSliceSampler, product_target(golden("traj_vmfmix_readme.npz")),
+                                 5000, seed=3)
+    s.advance(5)
+    assert s.n_chains == 5000 and np.all(s.errors == 0)
+    print("RCCL-OK")
+finally:
+    dist.destroy_process_group()
+"""
+
+
 def test_rccl_collectives_single_rank(gs):
     """The exact collective calls of the multi-GPU path (all_gather_into_tensor, all_reduce, barrier over
-    the 'nccl' = RCCL backend, device tensors) run on this box with one rank."""
-    import os
-    import torch
-    import torch.distributed as dist
-    from geosss_amd import ensemble
-    if dist.is_initialized():
-        pytest.skip("a process group already exists")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    the 'nccl' = RCCL backend, device tensors) run on this box with one rank.  In a child process with a time
+    limit: a communicator that does not come up on a box must not take the test session with it."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     try:
-        x = gs.sample_sphere_device(2, 1000, seed=1)
-        out = ensemble.gather_states(x, always_collective=True)
-        assert out.shape == x.shape and torch.equal(out, x)
-        t = torch.tensor([5, 7], dtype=torch.int64, device="cuda")
-        assert torch.equal(ensemble.reduce_sum(t.clone()), t)
-        dist.barrier()
-        lo, hi = ensemble.shard_bounds(1000)
-        assert (lo, hi) == (0, 1000)
-        s = ensemble.sharded_sampler(gs.ShrinkageSphericalSliceSampler, product_target(golden("traj_vmfmix_readme.npz")),
-                                     5000, seed=3)
-        s.advance(5)
-        assert s.n_chains == 5000 and np.all(s.errors == 0)
-    finally:
-        dist.destroy_process_group()
+        r = subprocess.run([sys.executable, "-c", _RCCL_BODY.format(root=ROOT, port=port)], capture_output=True,
+                           text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the RCCL communicator did not come up within 150 s on this box")
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, r.stderr[-3000:]
 
 
 # ------------------------------------------------------------------ round-2 regressions
