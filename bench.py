@@ -160,22 +160,20 @@ def numpy_port_baseline(workload, cores, n_steps=400):
             "sample": f"{n_steps} steps per chain, one chain per process"}
 
 
-def ess_per_sec(gs, pdf, d, seed, steps_per_sec_total, n_chains=512, n_draws=4000):
-    """Effective samples per second (secondary metric): mean over a chain subsample of
-    n_eff / n for the first coordinate with the reference's own estimator (geosss/utils.py:119-134,
-    restated batched in geosss_amd/diagnostics.py and run on the GPU), scaled to the measured
-    whole-job step rate; plus the mode occupancy of the same draws."""
-    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=1).T
-    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed)
-    s.advance(200)
-    X = s.sample(n_draws, as_tensor=True)                          # (chains, draws, dims), on the device
-    rel = float((gs.diagnostics.n_eff(X[:, :, 0]) / n_draws).mean().item())
+def ess_per_sec(gs, sampler, pdf, steps_per_sec_total, n_steps=4000, thin=4, lags=48):
+    """Effective samples per second (secondary metric) of the WHOLE ensemble of the timed run: the sampler kernels
+    accumulate the lag sums of the first coordinate per chain (gsss_run_args.stats_dev; no draws are stored -- at
+    10^6 chains x 4000 steps they would be 96 GB) and the reference's own estimator (utils.acf + the IAT heuristic,
+    geosss/utils.py:96-134, on the series thinned by `thin`) gives n_eff per chain; plus the mode occupancy."""
+    sampler.enable_stats(lags=lags)
+    sampler.advance(n_steps, thin=thin, keep=False)
+    r = sampler.stats()
+    rel = float((r["n_eff"] / r["n"]).mean().item()) / thin        # effective draws per chain-step
     out = {"ess_per_step": rel, "ess_per_sec": rel * steps_per_sec_total,
-           "estimator": f"geosss IAT heuristic on the first coordinate, {n_chains} chains x {n_draws} draws"}
-    if isinstance(pdf, gs.MixtureModel):
-        import torch
-        modes = torch.as_tensor(np.array([p.mu for p in pdf.pdfs]), device=X.device)
-        out["mode_occupancy"] = [float(v) for v in gs.diagnostics.mode_occupancy(X, modes).cpu()]
+           "estimator": f"geosss IAT heuristic on the running autocorrelation of the first coordinate (lags <= {lags} x {thin} "
+                        f"steps), all {sampler.n_chains} chains x {n_steps} steps, no stored draws"}
+    if "mode_occupancy" in r:
+        out["mode_occupancy"] = [float(v) for v in r["mode_occupancy"].mean(0).cpu()]
     return out
 
 
@@ -401,11 +399,11 @@ def main(argv=None):
                               "frac": flops_step * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
                               "flops_per_chain_step": flops_step},
         }
+        if world == 1 and not args.no_ess:
+            out["ess"] = ess_per_sec(gs, sampler, pdf, value)
         if world == 1 and not args.no_configs and args.workload == "vmfmix_readme":
             del sampler, kept
             out["configs"] = [time_config(gs, torch, name, nc, S) for name, nc in EXTRA_CONFIGS]
-        if world == 1 and not args.no_ess:
-            out["ess"] = ess_per_sec(gs, pdf, d, 3521, value)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -11,7 +11,7 @@ SHRINK, REJECT = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GsssError(RuntimeError):
@@ -31,7 +31,8 @@ class RunArgs(C.Structure):
                 ("seed", C.c_uint64), ("chain_offset", C.c_uint64), ("step_offset", C.c_uint64),
                 ("sampler", C.c_int32), ("mode", C.c_int32), ("max_tries", C.c_int32), ("variant", C.c_int32),
                 ("rng_state_dev", C.c_void_p), ("samples_chain_rows", C.c_int64), ("placement", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("stats_lags", C.c_int32), ("stats_dev", C.c_void_p), ("stats_dirs_dev", C.c_void_p),
+                ("stats_modes", C.c_int32), ("reserved", C.c_int32)]
 
 
 # symbol -> (restype, argtypes); must list every function include/gsss.h declares
@@ -44,6 +45,7 @@ SIGNATURES = {
     "gsss_target_dim": (C.c_int, [C.c_void_p]),
     "gsss_logprob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsss_run": (C.c_int, [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]),
+    "gsss_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gsss_mode_supported": (C.c_int, [C.c_void_p, C.c_int32]),
     "gsss_variant_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "gsss_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

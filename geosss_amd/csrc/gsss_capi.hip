@@ -482,6 +482,33 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     }
     rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= 2048) ? 1 : 0;
     rb.screen = (a->mode == GSSS_MODE_FAST && a->variant == GSSS_VARIANT_FAST_DOUBLE) ? 0 : 1;
+    rb.stats = a->stats_dev;
+    rb.stats_dirs = a->stats_dirs_dev;
+    rb.stats_lags = a->stats_lags;
+    rb.stats_modes = a->stats_modes;
+    if (a->stats_dev != nullptr) {
+        if (!a->stats_dirs_dev || a->stats_lags < 0 || a->stats_modes < 0 || a->stats_lags > 4096 || a->stats_modes > 4096) {
+            set_error("stats_dev needs stats_dirs_dev, 0 <= stats_lags <= 4096 and 0 <= stats_modes <= 4096");
+            return GSSS_E_INVALID;
+        }
+        bool lane;
+        if (a->mode == GSSS_MODE_FAST) {
+            FastProbe pr;
+            RunBlock rbp{};
+            if (fast_dispatch(t->tb, rbp, false, &pr, nullptr) != GSSS_OK) return GSSS_E_UNSUPPORTED;
+            lane = pr.lane;
+        } else {
+            int nv;
+            const VecInfo *v = vec_table(&nv);
+            lane = false;
+            for (int i = 0; i < nv; ++i)
+                if (v[i].id == vec) lane = v[i].L == 1;
+        }
+        if (!lane) {
+            set_error("running statistics are accumulated by the lane-per-chain kernels only (this shape runs a cooperative one)");
+            return GSSS_E_UNSUPPORTED;
+        }
+    }
     DeviceGuard guard(t->device);
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -512,6 +539,12 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     }
     set_error("corrupt target");
     return GSSS_E_INVALID;
+}
+
+int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags)
+{
+    if (d < 2 || n_modes < 0 || n_lags < 0) return GSSS_E_INVALID;
+    return 1 + 2 * (int64_t)d + (int64_t)d * (d + 1) / 2 + 2 + n_modes + 2 + 3 * (int64_t)n_lags;
 }
 
 int gsss_mode_supported(const gsss_target *t, int32_t mode)

@@ -45,12 +45,89 @@ struct RunBlock {
     int64_t keep_rows;  // > 0: samples are written chain-major [chain][keep_rows][d]; 0: [row][d][chain]
     int32_t spread;     // lane layouts: one chain per WAVEFRONT (small ensembles: no divergence between chains)
     int32_t screen;     // fast mode: tries are screened in single precision where the target's kernel is built for it
+    double *stats;             // NULL or [gsss_stats_rows][n_chains] running statistics of the retained series
+    const double *stats_dirs;  // [2 + stats_modes][d]: projection w, hop direction h, mode directions
+    int32_t stats_lags, stats_modes;
 };
 
 // address of component j of retained row `row` of chain c
 __device__ __forceinline__ size_t sample_index(const RunBlock &a, int64_t row, int j, int d, int64_t c)
 {
     return a.keep_rows > 0 ? ((size_t)c * a.keep_rows + row) * d + j : ((size_t)row * d + j) * a.n_chains + c;
+}
+
+// ------------------------------------------------------------------------------------------
+// Running statistics of the retained series (every thin-th state), accumulated per chain in HBM while the chain
+// is sampled, so that diagnostics need no stored draws (include/gsss.h: gsss_stats_rows, GSSS_STATS_*).
+// Definitions follow the reference's post-hoc estimators on a stored series s_0 .. s_{n-1}:
+//   sum s, sum s s^T                           (moments)
+//   sum_t distance(s_t, s_{t-1})               sphere.py:64-68 on consecutive draws
+//   #{t : sign(s_t.h) != sign(s_{t-1}.h)}      scripts/bingham.py:23-25 (hopping frequency)
+//   #{t : argmax_k s_t.mode_k = k}             scripts/vMF_diagnostics.py:335-342 (mode occupancy)
+//   p_t = s_t.w: sum p, sum p^2, sum_t p_t p_{t-l} (l = 1 .. L), first and last L values
+//                                              -> utils.acf (utils.py:96-110) exactly, IAT / n_eff by :119-134
+// Row r of chain c lives at stats[r * n_chains + c].  D components of the state in registers.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__device__ __noinline__ void stats_update(const RunBlock &a, int64_t c, const double (&x)[D])
+{
+    const size_t n = (size_t)a.n_chains;
+    double *s = a.stats + c;
+    const int K = a.stats_modes, L = a.stats_lags;
+    constexpr int T = D * (D + 1) / 2;
+    const int r_prev = 1, r_sum = 1 + D, r_xx = 1 + 2 * D, r_dist = r_xx + T, r_hop = r_dist + 1, r_mode = r_hop + 1;
+    const int r_p = r_mode + K, r_lag = r_p + 2, r_ring = r_lag + L, r_head = r_ring + L;
+    const double *w = a.stats_dirs, *h = a.stats_dirs + D, *modes = a.stats_dirs + 2 * D;
+    const int64_t cnt = (int64_t)s[0];
+    double p = 0.0, xh = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        p = fma(x[j], w[j], p);
+        xh = fma(x[j], h[j], xh);
+    }
+    if (cnt > 0) {
+        double dot = 0.0, ph = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double pj = s[(size_t)(r_prev + j) * n];
+            dot = fma(pj, x[j], dot);
+            ph = fma(pj, h[j], ph);
+        }
+        s[(size_t)r_dist * n] += acos(fmin(fmax(dot, -1.0), 1.0));
+        const int sa = (xh > 0.0) - (xh < 0.0), sb = (ph > 0.0) - (ph < 0.0);  // np.sign
+        if (sa != sb) s[(size_t)r_hop * n] += 1.0;
+    }
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        s[(size_t)(r_prev + i) * n] = x[i];
+        s[(size_t)(r_sum + i) * n] += x[i];
+#pragma unroll
+        for (int j = i; j < D; ++j) s[(size_t)(r_xx + t++) * n] += x[i] * x[j];
+    }
+    if (K > 0) {
+        int best = 0;
+        double bv = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) v = fma(x[j], modes[k * D + j], v);
+            if (v > bv) {  // first maximum, like np.argmax
+                bv = v;
+                best = k;
+            }
+        }
+        s[(size_t)(r_mode + best) * n] += 1.0;
+    }
+    s[(size_t)r_p * n] += p;
+    s[(size_t)(r_p + 1) * n] += p * p;
+    if (L > 0) {
+        const int64_t lmax = cnt < L ? cnt : L;
+        for (int64_t l = 1; l <= lmax; ++l) s[(size_t)(r_lag + l - 1) * n] += p * s[(size_t)(r_ring + (cnt - l) % L) * n];
+        s[(size_t)(r_ring + cnt % L) * n] = p;
+        if (cnt < L) s[(size_t)(r_head + cnt) * n] = p;
+    }
+    s[0] = (double)(cnt + 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -711,14 +788,17 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
         n_rej += step_err ? t : t - 1;
         err |= step_err;
 
-        if (a.samples != nullptr && --until_keep == 0) {
+        if ((a.samples != nullptr || a.stats != nullptr) && --until_keep == 0) {
             until_keep = a.thin;
-            if (active) {
+            if (active && a.samples != nullptr) {
 #pragma unroll
                 for (int i = 0; i < V::N; ++i) {
                     const int cc = V::comp(g, i);
                     if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
                 }
+            }
+            if constexpr (V::L == 1) {  // (cooperative layouts: refused by gsss_run)
+                if (active && a.stats != nullptr && !step_err) stats_update<V::N>(a, c, x);
             }
             ++row;
         }

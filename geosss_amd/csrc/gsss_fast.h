@@ -530,9 +530,12 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             cur.lvl = lvl;
             count_tries();
             ++cur.steps_done;
-            if (a.samples != nullptr && cur.steps_done == (cur.row + 1) * thin) {
+            if ((a.samples != nullptr || a.stats != nullptr) && cur.steps_done == (cur.row + 1) * thin) {
+                if (a.samples != nullptr) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                    for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                }
+                if (a.stats != nullptr) stats_update<D>(a, chain_id(), cur.x);
                 ++cur.row;
             }
             cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
@@ -1396,13 +1399,14 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
         }
         if (!accepted) break;
         ++steps_done;
-        if (a.samples != nullptr && --until_keep == 0) {
+        if ((a.samples != nullptr || a.stats != nullptr) && --until_keep == 0) {
             until_keep = a.thin;
-            if (lane < D) {
+            if (lane < D && a.samples != nullptr) {
 #pragma unroll
                 for (int j = 0; j < D; ++j)
                     if (lane == j) a.samples[sample_index(a, row, j, D, c)] = x[j];
             }
+            if (lane == 0 && a.stats != nullptr) stats_update<D>(a, c, x);
             ++row;
         }
     }

@@ -365,9 +365,12 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
             for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
             count_tries();
             ++cur.steps_done;
-            if (a.samples != nullptr && cur.steps_done == (cur.row + 1) * thin) {
+            if ((a.samples != nullptr || a.stats != nullptr) && cur.steps_done == (cur.row + 1) * thin) {
+                if (a.samples != nullptr) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                    for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                }
+                if (a.stats != nullptr) stats_update<D>(a, chain_id(), cur.x);
                 ++cur.row;
             }
             const bool exhausted = REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED);

@@ -13,7 +13,8 @@ the GPU.  One scalar series gives the reference's scalar.
 import numpy as np
 import torch
 
-__all__ = ["acf", "acf_fft", "IAT", "n_eff", "distance", "hopping_frequency", "mode_occupancy", "mode_kl"]
+__all__ = ["acf", "acf_fft", "IAT", "n_eff", "distance", "hopping_frequency", "mode_occupancy", "mode_kl", "from_running",
+           "iat_from_acf"]
 
 
 def _t(x):
@@ -101,3 +102,66 @@ def mode_kl(occupancy, weights):
     p = torch.where(p > 0, p, torch.full_like(p, 1e-100))
     w = _t(weights).to(p)
     return _back((p * torch.log(p / w)).sum(), occupancy)
+
+
+def iat_from_acf(ac):
+    """The IAT heuristic of utils.py:119-131 applied to a given autocorrelation (lags 0 .. m-1 along the last
+    axis): adjacent-pair sums from lag 2, truncated at the first negative pair."""
+    ac = _t(ac)
+    m = ac.shape[-1]
+    tail = ac[..., 2:-1] if m % 2 != 0 else ac[..., 2:]
+    sums = tail.reshape(*tail.shape[:-1], -1, 2).sum(-1)
+    neg = sums < 0
+    has = neg.any(-1)
+    first = torch.argmax(neg.to(torch.int64), dim=-1)
+    L = torch.where(has, 1 + 2 * first, torch.full_like(first, m - 1))
+    lag = torch.arange(m, device=ac.device)
+    keep = (lag >= 1) & (lag <= L.unsqueeze(-1))
+    return 1.0 + torch.clamp(2.0 * (ac * keep).sum(-1), min=0.0)
+
+
+def from_running(acc, d, n_modes, n_lags):
+    """Diagnostics from the running statistics the sampler kernels accumulate (include/gsss.h: gsss_run_args.stats_dev;
+    rows x chains).  Per chain, with the reference's definitions on the retained series:
+        n, mean (d), second_moment (d, d), geodesic_step (sphere.distance of consecutive draws, mean),
+        hopping_frequency (scripts/bingham.py:23-25), mode_occupancy (K; scripts/vMF_diagnostics.py:335-342),
+        acf (lags 0 .. L of the projection, the direct estimator utils.acf, utils.py:96-110 -- identical to
+        diagnostics.acf(series, n_max=L+1)), iat / n_eff (pair-sum heuristic of utils.py:119-134 on that acf)."""
+    acc = _t(acc).to(torch.float64)
+    T = d * (d + 1) // 2
+    r_sum, r_xx = 1 + d, 1 + 2 * d
+    r_dist = r_xx + T
+    r_hop, r_mode = r_dist + 1, r_dist + 2
+    r_p = r_mode + n_modes
+    r_lag, r_ring, r_head = r_p + 2, r_p + 2 + n_lags, r_p + 2 + 2 * n_lags
+    n = acc[0]
+    out = {"n": n, "mean": (acc[r_sum:r_sum + d] / n).T}
+    sm = torch.zeros((acc.shape[1], d, d), dtype=torch.float64, device=acc.device)
+    iu = torch.triu_indices(d, d)
+    sm[:, iu[0], iu[1]] = (acc[r_xx:r_xx + T] / n).T
+    sm[:, iu[1], iu[0]] = (acc[r_xx:r_xx + T] / n).T
+    out["second_moment"] = sm
+    out["geodesic_step"] = acc[r_dist] / (n - 1)
+    out["hopping_frequency"] = acc[r_hop] / (n - 1)
+    if n_modes:
+        out["mode_occupancy"] = (acc[r_mode:r_mode + n_modes] / n).T
+    if n_lags:
+        L = n_lags
+        if bool((n <= L).any()):
+            raise ValueError("the autocorrelation needs more than `lags` retained draws per chain")
+        sp, spp = acc[r_p], acc[r_p + 1]
+        mu = sp / n
+        lag = torch.arange(1, L + 1, device=acc.device, dtype=torch.float64)[:, None]
+        head = torch.cumsum(acc[r_head:r_head + L], dim=0)                    # sum of the first l values
+        # the last l values: ring slot (n - j) mod L holds p_{n-j}, j = 1 .. L
+        j = torch.arange(1, L + 1, device=acc.device)[:, None]
+        slot = torch.remainder(n.to(torch.int64)[None, :] - j, L)
+        tail = torch.cumsum(torch.gather(acc[r_ring:r_ring + L], 0, slot), dim=0)
+        c = acc[r_lag:r_lag + L]
+        cov = (c - mu * ((sp - head) + (sp - tail)) + (n - lag) * mu * mu) / (n - lag)
+        var = (spp - n * mu * mu) / n
+        ac = torch.cat([torch.ones_like(var)[None], cov / var], dim=0).T     # (chains, L + 1)
+        out["acf"] = ac
+        out["iat"] = iat_from_acf(ac)
+        out["n_eff"] = n / out["iat"]
+    return out

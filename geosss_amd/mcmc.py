@@ -143,6 +143,45 @@ class RejectionSphericalSliceSampler:
         self._err = torch.zeros(n, dtype=torch.int32, device=self._tdev)
         self._tries_reported = 0
         self._rng_state = self._numpy_states(seed) if rng == "numpy" else None
+        self._stats = None
+
+    # ------------------------------------------------------------------ running statistics
+    def enable_stats(self, lags=32, projection=None, hop=None, modes=None):
+        """Accumulate running statistics of the retained series inside the sampler kernels (gsss_run_args.stats_dev):
+        moments, geodesic step between consecutive draws, hopping frequency across the equator of `hop`, occupancy
+        of `modes`, and the lag sums of the projection x . `projection` from which the reference's autocorrelation
+        (utils.py:96-110) and its IAT / n_eff heuristic (:119-134) follow -- without storing a single draw.
+        Statistics are taken at the cadence of `advance(..., thin=t)` (every t-th state), like diagnostics computed
+        from a thinned stored chain.  Defaults: projection = first coordinate; hop = the target's `.mode` if it has
+        one; modes = the component means of a MixtureModel.  Lane-per-chain kernels only (d <= 10 in exact mode)."""
+        d = self.d
+        w = np.zeros(d) if projection is None else np.asarray(projection, dtype=np.float64)
+        if projection is None:
+            w[0] = 1.0
+        if hop is None:
+            hop = getattr(self.target, "mode", None)
+            hop = np.zeros(d) if hop is None or np.ndim(hop) != 1 else hop
+        if modes is None:
+            pdfs = getattr(self.target, "pdfs", None)
+            modes = np.array([p.mu for p in pdfs]) if pdfs else np.zeros((0, d))
+        modes = np.asarray(modes, dtype=np.float64).reshape(-1, d)
+        dirs = np.concatenate([w[None], np.asarray(hop, dtype=np.float64)[None], modes], axis=0)
+        if dirs.shape[1] != d:
+            raise ValueError("projection / hop / modes must have d components")
+        rows = int(self._lib.gsss_stats_rows(d, len(modes), int(lags)))
+        if rows < 0:
+            raise ValueError("bad statistics shape")
+        self._stats = {"lags": int(lags), "modes": len(modes),
+                       "dirs": torch.from_numpy(np.ascontiguousarray(dirs)).to(self._tdev),
+                       "acc": torch.zeros((rows, self.n_chains), dtype=torch.float64, device=self._tdev)}
+        return self
+
+    def stats(self):
+        """The running statistics as a dict of CUDA tensors, one entry per chain (see diagnostics.from_running)."""
+        if self._stats is None:
+            raise ValueError("call enable_stats() first")
+        from . import diagnostics
+        return diagnostics.from_running(self._stats["acc"], self.d, self._stats["modes"], self._stats["lags"])
 
     def _numpy_states(self, seed):
         """[n_chains, 4] PCG64 words (state_hi, state_lo, inc_hi, inc_lo), one default_rng per chain:
@@ -289,7 +328,7 @@ class RejectionSphericalSliceSampler:
             self._sync_rng()
 
     # ------------------------------------------------------------------ running
-    def _launch(self, n_steps, samples=None, thin=1, replay=None, chain_rows=0, samples_ptr=None):
+    def _launch(self, n_steps, samples=None, thin=1, replay=None, chain_rows=0, samples_ptr=None, stats=False):
         a = _lib.RunArgs()
         a.state_dev = self._state.data_ptr()
         a.samples_dev = samples_ptr if samples_ptr is not None else (samples.data_ptr() if samples is not None else None)
@@ -315,10 +354,14 @@ class RejectionSphericalSliceSampler:
             if replay is not None:
                 raise ValueError("replay and rng='numpy' are mutually exclusive")
             a.rng_state_dev = self._rng_state.data_ptr()
+        if self._stats is not None and stats:
+            a.stats_dev = self._stats["acc"].data_ptr()
+            a.stats_dirs_dev = self._stats["dirs"].data_ptr()
+            a.stats_lags, a.stats_modes = self._stats["lags"], self._stats["modes"]
         _lib.check(self._lib.gsss_run(self._target_dev.handle, C.byref(a), self._stream()))
         self._step += int(n_steps)
 
-    def advance(self, n_steps, *, thin=None, out=None, replay=None, chain_major=False, row0=0):
+    def advance(self, n_steps, *, thin=None, out=None, replay=None, chain_major=False, row0=0, keep=True):
         """Advance every chain by n_steps transitions on the GPU (asynchronously).
 
         thin=None keeps nothing; thin=t >= 1 keeps the state after every t-th step and returns a
@@ -327,6 +370,8 @@ class RejectionSphericalSliceSampler:
         (n_chains, R, d) tensor in the reference's (chains, draws, dims) order (every chain appends to
         its own contiguous run; no layout pass afterwards).
         `replay` (n_chains, stride) replays recorded draws instead of the Philox stream.
+        keep=False with thin=t stores nothing and only feeds the running statistics (enable_stats) with every
+        t-th state; with keep=True they are fed with the very states that are stored.
         """
         n_steps = int(n_steps)
         if n_steps < 0:
@@ -348,6 +393,16 @@ class RejectionSphericalSliceSampler:
         if thin < 1:
             raise ValueError("thin must be >= 1")
         n_keep = n_steps // thin
+        if not keep:
+            if self._stats is None:
+                raise ValueError("keep=False only makes sense with enable_stats()")
+            per = max(thin, (_MAX_STEPS_PER_LAUNCH // thin) * thin)
+            done = 0
+            while done < n_steps:
+                m = min(per, n_steps - done)
+                self._launch(m, thin=thin, stats=True)
+                done += m
+            return None
         if chain_major:
             if (out is None or out.ndim != 3 or out.shape[0] != self.n_chains or out.shape[2] != self.d
                     or out.dtype != torch.float64 or not out.is_contiguous() or row0 + n_keep > out.shape[1]):
@@ -368,14 +423,14 @@ class RejectionSphericalSliceSampler:
             def ptr(r):
                 return out.data_ptr() + 8 * self.d * self.n_chains * r
         if replay is not None:
-            self._launch(n_steps, thin=thin, replay=replay, chain_rows=total, samples_ptr=ptr(0))
+            self._launch(n_steps, thin=thin, replay=replay, chain_rows=total, samples_ptr=ptr(0), stats=True)
             return out
         per = max(thin, (_MAX_STEPS_PER_LAUNCH // thin) * thin)
         done = 0
         while done < n_steps:
             m = min(per, n_steps - done)
             if m // thin:
-                self._launch(m, thin=thin, chain_rows=total, samples_ptr=ptr(done // thin))
+                self._launch(m, thin=thin, chain_rows=total, samples_ptr=ptr(done // thin), stats=True)
             else:
                 self._launch(m)
             done += m

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 4
+#define GSSS_ABI_VERSION 5
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -132,6 +132,27 @@ typedef struct gsss_run_args {
     int32_t placement;         /* lane-per-chain kernels: 0 = library's choice (spread for <= 2048 chains), 1 = packed
                                   (64 chains per wavefront: throughput), 2 = spread (one chain per wavefront: chains of a
                                   small ensemble do not wait for each other's shrink loops; same numbers either way) */
+    int32_t stats_lags;        /* L >= 0: lags of the running autocovariance sums (see stats_dev) */
+    double *stats_dev;         /* NULL or [gsss_stats_rows(d, stats_modes, stats_lags)][n_chains]: running statistics of the RETAINED
+                                  series (every thin-th state, whether or not samples_dev is given), ADDED to across calls, so that
+                                  moments, geodesic step, hopping frequency, mode occupancy and the autocorrelation / IAT / ESS of one
+                                  projection need no stored draws (geosss/utils.py:96-134, sphere.py:64-68, scripts/bingham.py:23-25,
+                                  scripts/vMF_diagnostics.py:335-342).  Zero it before the first call.  Rows, with T = d (d + 1) / 2,
+                                  K = stats_modes, L = stats_lags:
+                                    0                count n of retained draws
+                                    1 .. d           the last retained draw
+                                    .. + d           sum of the draws
+                                    .. + T           sum of x_i x_j, i <= j, row-major upper triangle
+                                    .. + 1           sum over consecutive draws of arccos(clip(x_t . x_{t-1}, -1, 1))
+                                    .. + 1           number of consecutive draws with sign(x_t . h) != sign(x_{t-1} . h)
+                                    .. + K           number of draws whose first-largest x . mode_k is k
+                                    .. + 2           sum p, sum p^2 of the projection p_t = x_t . w
+                                    .. + L           sum_t p_t p_{t-l}, l = 1 .. L
+                                    .. + L           ring of the last L values of p (slot t mod L)
+                                    .. + L           the first L values of p
+                                  Lane-per-chain kernels only (d <= 10 exact, the lane fast kernels); GSSS_E_UNSUPPORTED otherwise */
+    const double *stats_dirs_dev; /* [2 + stats_modes][d]: w, h, then the mode directions; required with stats_dev */
+    int32_t stats_modes;       /* K >= 0 */
     int32_t reserved;
 } gsss_run_args;
 
@@ -152,6 +173,9 @@ int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *o
 
 /* The sampler (see gsss_run_args). */
 int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);
+
+/* Number of rows of gsss_run_args.stats_dev for dimension d, K modes and L lags (< 0: bad argument). */
+int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags);
 
 /* 1 if gsss_run accepts `mode` for this target's shape (fast mode is built for the shapes listed in
  * geosss_amd/csrc/gsss_fast_*.hip), else 0. */

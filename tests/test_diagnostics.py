@@ -38,3 +38,64 @@ def test_diagnostics_cpu():
 def test_diagnostics_gpu():
     from geosss_amd import diagnostics as dg
     _check(dg, "cuda")
+
+
+def running_rows(d, n_modes, n_lags):
+    return 1 + 2 * d + d * (d + 1) // 2 + 2 + n_modes + 2 + 3 * n_lags
+
+
+def accumulate_numpy(X, w, h, modes, L):
+    """What the sampler kernels accumulate per retained draw (gsss_device.h: stats_update), restated in numpy for one
+    chain: the fixture for the host-side derivations."""
+    n, d = X.shape
+    K = len(modes)
+    acc = np.zeros(running_rows(d, K, L))
+    T = d * (d + 1) // 2
+    r_prev, r_sum, r_xx = 1, 1 + d, 1 + 2 * d
+    r_dist = r_xx + T
+    r_hop, r_mode = r_dist + 1, r_dist + 2
+    r_p = r_mode + K
+    r_lag, r_ring, r_head = r_p + 2, r_p + 2 + L, r_p + 2 + 2 * L
+    iu = np.triu_indices(d)
+    for t, x in enumerate(X):
+        p = x @ w
+        if t > 0:
+            prev = acc[r_prev:r_prev + d]
+            acc[r_dist] += np.arccos(np.clip(prev @ x, -1, 1))
+            acc[r_hop] += float(np.sign(x @ h) != np.sign(prev @ h))
+        acc[r_prev:r_prev + d] = x
+        acc[r_sum:r_sum + d] += x
+        acc[r_xx:r_xx + T] += np.outer(x, x)[iu]
+        if K:
+            acc[r_mode + int(np.argmax(modes @ x))] += 1
+        acc[r_p] += p
+        acc[r_p + 1] += p * p
+        for l in range(1, min(L, t) + 1):
+            acc[r_lag + l - 1] += p * acc[r_ring + (t - l) % L]
+        acc[r_ring + t % L] = p
+        if t < L:
+            acc[r_head + t] = p
+        acc[0] = t + 1
+    return acc
+
+
+def test_running_statistics_host_math_against_reference_kat():
+    """diagnostics.from_running turns the kernels' accumulators into the reference's estimators: utils.acf exactly
+    (utils.py:96-110), sphere.distance of consecutive draws, mode occupancy, hopping frequency -- checked against the
+    values geosss itself produced for the same series (diagnostics_kat.npz)."""
+    from geosss_amd import diagnostics as dg
+    z = golden("diagnostics_kat.npz")
+    X, modes, L = z["vmf_X"], z["vmf_modes"], 49
+    accs = np.stack([accumulate_numpy(X, np.eye(3)[j], modes[0], modes, L) for j in range(3)], axis=1)
+    assert int(dg.__dict__["_t"](accs).shape[0]) == running_rows(3, 3, L)
+    r = dg.from_running(torch.as_tensor(accs), 3, 3, L)
+    assert np.allclose(r["acf"].numpy(), z["vmf_acf"], rtol=0, atol=1e-11)            # lags 0 .. 49 of each coordinate
+    assert np.allclose(r["geodesic_step"].numpy(), z["vmf_distance"].mean(), rtol=1e-12)
+    assert np.allclose(r["mode_occupancy"].numpy(), z["vmf_occupancy"][None], atol=1e-15)
+    assert np.allclose(r["mean"][0].numpy(), X.mean(0), atol=1e-13)
+    assert np.allclose(r["second_moment"][0].numpy(), X.T @ X / len(X), atol=1e-13)
+    want_iat = dg.iat_from_acf(torch.as_tensor(z["vmf_acf"])).numpy()
+    assert np.allclose(r["iat"].numpy(), want_iat, rtol=1e-9)
+    Xb, mode = z["bingham_X"], z["bingham_mode"]
+    rb = dg.from_running(torch.as_tensor(accumulate_numpy(Xb, np.eye(10)[0], mode, np.zeros((0, 10)), 8)[:, None]), 10, 0, 8)
+    assert abs(float(rb["hopping_frequency"][0]) - float(z["bingham_hop"])) < 1e-15

@@ -205,3 +205,78 @@ def test_bingham_d50_geodesic_step(gs):
         assert np.all(s.errors == 0)
         geo = torch.arccos(torch.clamp((s.state_rows() * prev).sum(1), -1, 1)).mean().item()
         assert abs(geo - want) < tol, (cls.__name__, geo)
+
+
+# ------------------------------------------------------------------ running statistics inside the sampler kernels
+
+
+@pytest.mark.parametrize("name,mode,placement,n_chains", [
+    ("vmfmix_readme", "fast", "packed", 3000), ("vmfmix_readme", "fast", "spread", 64), ("vmfmix_readme", "exact", "packed", 500),
+    ("vmfmix_k10_kappa500", "fast", "packed", 1000), ("bingham_d10_vmax30", "fast", "packed", 1500),
+    ("bingham_d10_vmax30", "exact", "packed", 300), ("curve_d10_kappa800", "fast", "packed", 700),
+    ("vmfmix_d4_k4_weighted", "fast", "packed", 900)])
+def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placement, n_chains):
+    """The accumulators the kernels keep per chain (gsss_run_args.stats_dev) give the very numbers the reference's
+    post-hoc estimators give on the stored draws: moments, geodesic step, hopping frequency, mode occupancy, the
+    autocorrelation utils.acf and the IAT heuristic on it -- 1e-12; and feeding them without storing anything
+    (keep=False) accumulates the same bits."""
+    import torch
+    from conftest import golden
+    from helpers import product_target
+    dg = gs.diagnostics
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=5).T
+    L, thin, n_keep = 24, 3, 400
+    w = np.linspace(1.0, 2.0, d)
+    hop = getattr(pdf, "mode", np.eye(d)[1])
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=11, mode=mode, placement=placement).enable_stats(lags=L, projection=w, hop=hop)
+    s.advance(50)                                                   # burn-in: not part of the statistics
+    kept = torch.cat([s.advance(n_keep // 2 * thin, thin=thin), s.advance(n_keep // 2 * thin, thin=thin)])  # two launches
+    X = kept.permute(2, 0, 1).contiguous()                          # (chains, draws, dims)
+    r = s.stats()
+    assert torch.equal(r["n"], torch.full((n_chains,), float(n_keep), dtype=torch.float64, device=X.device))
+    assert torch.allclose(r["mean"], X.mean(1), rtol=0, atol=1e-13)
+    assert torch.allclose(r["second_moment"], torch.einsum("cti,ctj->cij", X, X) / n_keep, rtol=0, atol=1e-13)
+    assert torch.allclose(r["geodesic_step"], dg.distance(X[:, 1:], X[:, :-1]).mean(1), rtol=1e-12, atol=1e-14)
+    assert torch.allclose(r["hopping_frequency"], dg.hopping_frequency(X, hop), rtol=0, atol=1e-15)
+    if isinstance(pdf, gs.MixtureModel):
+        modes = torch.as_tensor(np.array([p.mu for p in pdf.pdfs]), device=X.device)
+        for c in (0, n_chains // 2, n_chains - 1):
+            assert torch.allclose(r["mode_occupancy"][c], dg.mode_occupancy(X[c], modes), rtol=0, atol=1e-15)
+    P = X @ torch.as_tensor(w, device=X.device)
+    assert torch.allclose(r["acf"], dg.acf(P, L + 1), rtol=0, atol=1e-11)
+    assert torch.allclose(r["iat"], dg.iat_from_acf(dg.acf(P, L + 1)), rtol=1e-9)
+    # the same statistics without storing a draw
+    t = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=11, mode=mode, placement=placement).enable_stats(lags=L, projection=w, hop=hop)
+    t.advance(50)
+    t.advance(n_keep * thin, thin=thin, keep=False)
+    assert torch.equal(t._stats["acc"], s._stats["acc"])
+
+
+def test_running_statistics_refused_for_cooperative_layouts(gs):
+    from conftest import golden
+    from helpers import product_target
+    pdf = product_target(golden("traj_curve_d50_kappa800.npz"))
+    s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere(49, 8, seed=1), seed=1).enable_stats(lags=4)
+    with pytest.raises(ValueError, match="lane-per-chain"):
+        s.advance(10, thin=1, keep=False)
+
+
+def test_ess_at_full_ensemble_size_without_stored_draws(gs):
+    """ESS of 200 000 chains x 20 000 steps (4e9 chain-steps; the draws would be 96 GB) from the running lag sums;
+    agrees with the reference chains' own n_eff per step (stats_vmfmix_readme.npz) to the spread between chains."""
+    from conftest import golden
+    from helpers import product_target
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    n = 200_000
+    s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere_device(2, n, seed=3).T, seed=9).enable_stats(lags=60)
+    s.advance(200)
+    s.advance(4000 * 5, thin=5, keep=False)
+    r = s.stats()
+    rel = float((r["n_eff"] / r["n"]).mean().item()) / 5.0          # effective draws per chain-step
+    assert 0.02 < rel < 0.06, rel                                    # IAT of the first coordinate ~ 30 steps (DESIGN.md)
+    occ = r["mode_occupancy"].mean(0).cpu().numpy()
+    assert np.max(np.abs(occ - 1 / 3)) < 0.01
