@@ -69,7 +69,7 @@ __device__ __forceinline__ size_t sample_index(const RunBlock &a, int64_t row, i
 // Row r of chain c lives at stats[r * n_chains + c].  D components of the state in registers.
 // ------------------------------------------------------------------------------------------
 template <int D>
-__device__ __noinline__ void stats_update(const RunBlock &a, int64_t c, const double (&x)[D])
+__device__ __forceinline__ void stats_update(const RunBlock &a, int64_t c, const double (&x)[D])
 {
     const size_t n = (size_t)a.n_chains;
     double *s = a.stats + c;
@@ -679,7 +679,7 @@ __host__ __device__ constexpr size_t scratch_doubles()
     return (size_t)T::kScratchPerChain * (kBlock / V::L);
 }
 
-template <class V, template <class> class TT, template <class> class DR>
+template <class V, template <class> class TT, template <class> class DR, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
 {
     using T = TT<V>;
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
         n_rej += step_err ? t : t - 1;
         err |= step_err;
 
-        if ((a.samples != nullptr || a.stats != nullptr) && --until_keep == 0) {
+        if ((a.samples != nullptr || STATS) && --until_keep == 0) {
             until_keep = a.thin;
             if (active && a.samples != nullptr) {
 #pragma unroll
@@ -797,8 +797,8 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
                     if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
                 }
             }
-            if constexpr (V::L == 1) {  // (cooperative layouts: refused by gsss_run)
-                if (active && a.stats != nullptr && !step_err) stats_update<V::N>(a, c, x);
+            if constexpr (STATS && V::L == 1) {  // (cooperative layouts: refused by gsss_run)
+                if (active && !step_err) stats_update<V::N>(a, c, x);
             }
             ++row;
         }

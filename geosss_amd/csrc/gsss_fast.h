@@ -66,12 +66,15 @@ struct FastVmf {
     };
     static constexpr int kCoefWords = 2 * KC + 1;
     __host__ __device__ static size_t lds_doubles() { return (size_t)KC * D + KC; }
+    int K;  // components of the target, K <= KC: the kernels are built for KC, the surplus ones are padded with
+            // mu = 0, logc = log(0), so that they add exactly +0.0 to every sum (a mixture of any K <= KC runs the KC kernel)
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
-        for (int i = threadIdx.x; i < KC * D; i += kBlock) lds[i] = tb.blob[i];
+        K = tb.k;
+        for (int i = threadIdx.x; i < KC * D; i += kBlock) lds[i] = i < K * D ? tb.blob[i] : 0.0;
         // a zero-weight component has logc = -inf (log w_k, distributions.py:220); exp_bounded wants finite
         // arguments, and e^{-1e5} is as much a zero as e^{-inf}
-        for (int i = threadIdx.x; i < KC; i += kBlock) lds[KC * D + i] = fmax(tb.blob[KC * D + i], kLogZero);
+        for (int i = threadIdx.x; i < KC; i += kBlock) lds[KC * D + i] = i < K ? fmax(tb.blob[K * D + i], kLogZero) : kLogZero;
         mu = lds;
         logc = lds + KC * D;
     }
@@ -371,7 +374,7 @@ __host__ __device__ constexpr size_t fast_lds_doubles()
                                 : 0);
 }
 
-template <int D, class TP, bool REPLAY>
+template <int D, class TP, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
@@ -530,12 +533,12 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             cur.lvl = lvl;
             count_tries();
             ++cur.steps_done;
-            if ((a.samples != nullptr || a.stats != nullptr) && cur.steps_done == (cur.row + 1) * thin) {
+            if ((a.samples != nullptr || STATS) && cur.steps_done == (cur.row + 1) * thin) {
                 if (a.samples != nullptr) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
                 }
-                if (a.stats != nullptr) stats_update<D>(a, chain_id(), cur.x);
+                if constexpr (STATS) stats_update<D>(a, chain_id(), cur.x);
                 ++cur.row;
             }
             cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
@@ -655,7 +658,10 @@ template <int D, class TP, bool REPLAY>
 int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
     const size_t lds = fast_lds_doubles<D, TP, REPLAY>() * sizeof(double);
-    auto kern = fast_kernel<D, TP, REPLAY>;
+    auto kern = fast_kernel<D, TP, REPLAY, false>;
+    if constexpr (!REPLAY) {  // running statistics: a build of its own (the plain kernel carries none of it)
+        if (rb.stats != nullptr) kern = fast_kernel<D, TP, false, true>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -842,9 +848,13 @@ struct CoopVmf {
     __host__ __device__ static size_t lds_doubles() { return (size_t)KC * V::DPAD + KC; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
-        lds_fill(lds, KC, V::DPAD, tb.blob, tb.d);
+        // K = tb.k <= KC components; the surplus rows are zeros with logc = log 0 (exact zeros in every sum)
+        lds_fill(lds, tb.k, V::DPAD, tb.blob, tb.d);
+        for (int i = threadIdx.x + tb.k * V::DPAD; i < KC * V::DPAD; i += kBlock) lds[i] = 0.0;
         double *lc = lds + (size_t)KC * V::DPAD;
-        for (int i = threadIdx.x; i < KC; i += kBlock) lc[i] = fmax(tb.blob[(size_t)KC * tb.d + i], kLogZero);
+        for (int i = threadIdx.x; i < KC; i += kBlock)
+            lc[i] = i < tb.k ? fmax(tb.blob[(size_t)tb.k * tb.d + i], kLogZero) : kLogZero;
+        sc.K = tb.k;
         rows = lds;
         sc.mu = lds;
         sc.logc = lc;
@@ -1222,7 +1232,7 @@ __device__ __forceinline__ double lane_broadcast_dyn(double v, int lane)  // `la
 // NUMPY = true: the draws come from numpy's own PCG64 / ziggurat stream (sequential by nature: every lane
 // runs the identical generator; lane t snapshots the generator after try t's uniform, and the accepted
 // try's snapshot becomes the stream position, so exactly the reference's numbers are consumed).
-template <int D, class TP, bool NUMPY>
+template <int D, class TP, bool NUMPY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
@@ -1399,14 +1409,16 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
         }
         if (!accepted) break;
         ++steps_done;
-        if ((a.samples != nullptr || a.stats != nullptr) && --until_keep == 0) {
+        if ((a.samples != nullptr || STATS) && --until_keep == 0) {
             until_keep = a.thin;
             if (lane < D && a.samples != nullptr) {
 #pragma unroll
                 for (int j = 0; j < D; ++j)
                     if (lane == j) a.samples[sample_index(a, row, j, D, c)] = x[j];
             }
-            if (lane == 0 && a.stats != nullptr) stats_update<D>(a, c, x);
+            if constexpr (STATS) {
+                if (lane == 0) stats_update<D>(a, c, x);
+            }
             ++row;
         }
     }
@@ -1426,7 +1438,8 @@ int do_wave(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     static_assert(16 % kSpecTries == 0 && (D + 1) / 2 <= 8 && (D + 3) / 4 <= 55, "Box-Muller pairs must fit the lanes reserved for them");
     const bool numpy = rb.rng_state != nullptr;
     const size_t lds = (TP::lds_doubles() + (numpy ? NumpyDraws<LaneVec<D>>::kLdsDoubles : 0)) * sizeof(double);
-    auto kern = numpy ? wave_kernel<D, TP, true> : wave_kernel<D, TP, false>;
+    auto kern = numpy ? wave_kernel<D, TP, true, false> : wave_kernel<D, TP, false, false>;
+    if (rb.stats != nullptr) kern = numpy ? wave_kernel<D, TP, true, true> : wave_kernel<D, TP, false, true>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

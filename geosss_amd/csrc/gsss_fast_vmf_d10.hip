@@ -1,0 +1,5 @@
+// lane-per-chain vMF-mixture kernels at d = 10 (see gsss_fast_vmf_lane.h)
+#include "gsss_fast_vmf_lane.h"
+namespace gsss {
+template int lane_vmf<10>(const TargetBlock &, const RunBlock &, bool, FastProbe *, hipStream_t);
+}

@@ -1,0 +1,48 @@
+// Lane-per-chain fast kernels for von Mises-Fisher mixtures, any K <= 16 components at d = 3 .. 10.
+//
+// Kernels are built per dimension and per component-count BUCKET KC: a mixture of K components runs the
+// kernel of the smallest bucket >= K (FastVmf::stage pads the surplus components with mu = 0, logc = log 0:
+// exact zeros in every sum, so the bucket does not change a single bit of the chain).  Screened kernels
+// (gsss_screen.h): buckets 3, 4, 6, 10, 16; the all-double fallback and the one-wavefront-per-chain kernels
+// (gsss_fast.h): buckets 4 and 16.  One translation unit per dimension (compile time).
+#pragma once
+#include "gsss_screen.h"
+
+namespace gsss {
+
+constexpr double kScreenMaxKappa = 4000.0;  // margin ~ 2e-6 kappa: beyond this a few per cent of the tries stay undecided
+
+// the screened kernel unless the caller forces all-double arithmetic, the ensemble is small (one wavefront per
+// chain), numpy's stream is asked for, or the concentration is so large that the margin would leave tries undecided
+template <int D, int KS, int KF>
+static int run_lane_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
+{
+    const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr && tb.scale <= kScreenMaxKappa;
+    if (!screen) return do_fast<D, FastVmf<D, KF>>(tb, rb, replay, st);
+    return replay ? do_screened_run<D, ScreenVmf<D, KS>, true>(tb, rb, st) : do_screened_run<D, ScreenVmf<D, KS>, false>(tb, rb, st);
+}
+
+template <int D>
+int lane_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
+{
+    const int ks = tb.k <= 3 ? 3 : (tb.k <= 4 ? 4 : (tb.k <= 6 ? 6 : (tb.k <= 10 ? 10 : 16)));
+    const int kf = tb.k <= 4 ? 4 : 16;
+    if (probe) {
+        if (rb.screen && tb.scale <= kScreenMaxKappa) GSSS_PROBE(true, "screened_kernel<%d, ScreenVmf<%d, %d>>", D, D, ks);
+        GSSS_PROBE(true, "fast_kernel<%d, FastVmf<%d, %d>>", D, D, kf);
+    }
+    switch (ks) {
+    case 3: return run_lane_vmf<D, 3, 4>(tb, rb, replay, st);
+    case 4: return run_lane_vmf<D, 4, 4>(tb, rb, replay, st);
+    case 6: return run_lane_vmf<D, 6, 16>(tb, rb, replay, st);
+    case 10: return run_lane_vmf<D, 10, 16>(tb, rb, replay, st);
+    default: return run_lane_vmf<D, 16, 16>(tb, rb, replay, st);
+    }
+}
+
+#define GSSS_VMF_LANE_DIMS(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#define GSSS_DECLARE(D) extern template int lane_vmf<D>(const TargetBlock &, const RunBlock &, bool, FastProbe *, hipStream_t);
+GSSS_VMF_LANE_DIMS(GSSS_DECLARE)
+#undef GSSS_DECLARE
+
+}  // namespace gsss

@@ -111,7 +111,8 @@ struct ScreenVmf : FastVmf<D, KC> {
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             q[2 * KC + k] -= t2;
-            b = fmaxf(b, fabsf(q[k]) + fabsf(q[KC + k]) + fabsf(q[2 * KC + k]) + fabsf(t2));
+            // (padding components beyond K have exponent -1e5: they add +0 to every sum and carry no error)
+            if (k < this->K) b = fmaxf(b, fabsf(q[k]) + fabsf(q[KC + k]) + fabsf(q[2 * KC + k]) + fabsf(t2));
         }
         // error of one exponent of a try: (|ax| + |au|) (eps_sincos + 2^-24) + |lc| 2^-24 + two fma roundings, plus the
         // error of log2 thr: three roundings per exponent of s0, v_exp_f32, the additions, v_log_f32 twice, the subtraction
@@ -182,7 +183,7 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
     b = __uint_as_float((uint32_t)(o >> 32));
 }
 
-template <int D, class TP, bool REPLAY>
+template <int D, class TP, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
@@ -365,12 +366,12 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
             for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
             count_tries();
             ++cur.steps_done;
-            if ((a.samples != nullptr || a.stats != nullptr) && cur.steps_done == (cur.row + 1) * thin) {
+            if ((a.samples != nullptr || STATS) && cur.steps_done == (cur.row + 1) * thin) {
                 if (a.samples != nullptr) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
                 }
-                if (a.stats != nullptr) stats_update<D>(a, chain_id(), cur.x);
+                if constexpr (STATS) stats_update<D>(a, chain_id(), cur.x);
                 ++cur.row;
             }
             const bool exhausted = REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
@@ -504,7 +505,10 @@ template <int D, class TP, bool REPLAY>
 int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
     const size_t lds = screen_lds_doubles<D, TP, REPLAY>() * sizeof(double);
-    auto kern = screened_kernel<D, TP, REPLAY>;
+    auto kern = screened_kernel<D, TP, REPLAY, false>;
+    if constexpr (!REPLAY) {  // running statistics: a build of its own (the plain kernel carries none of it)
+        if (rb.stats != nullptr) kern = screened_kernel<D, TP, false, true>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -48,7 +48,7 @@ def fast_supported(z, prefix="target_"):
     kind = str(z[prefix + "kind"])
     if kind == "vmf_mixture":
         k, d = z[prefix + "mu"].shape
-        return (d, k) in FAST_VMF or (k in (3, 5, 10) and 10 < d <= 256)  # cooperative fast kernels
+        return k <= 16 and d <= 256  # lane kernels d <= 10 (component buckets), cooperative fast kernels beyond
     if kind == "bingham":
         d = z[prefix + "A"].shape[0]
         return d in FAST_BINGHAM or 10 < d <= 128  # cooperative fast kernels

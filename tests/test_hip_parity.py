@@ -255,7 +255,9 @@ def test_layout_round_trip(gs):
 SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
          ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7),
          ("curve", 9, 10), ("curve", 15, 10), ("curve", 18, 10), ("curve", 21, 10), ("bingham", 7, 0), ("bingham", 9, 0),
-         ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10)]
+         ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10),
+         # any K <= 16 at any d: component buckets with exact padding (MixtureModel takes any K, distributions.py:209-227)
+         ("vmf", 3, 7), ("vmf", 6, 3), ("vmf", 8, 13), ("vmf", 9, 16), ("vmf", 4, 1), ("vmf", 7, 4), ("vmf", 30, 7), ("vmf", 100, 12)]
 
 
 @pytest.mark.parametrize("kind,d,k", SYNTH)
@@ -278,11 +280,14 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
     n_chains, n_steps = (70, 12) if d > 64 else (333, 25)
     x0 = oracle.sample_sphere(3, n_chains, d)
     want = oracle.run(tgt, x0, n_steps, seed=77, n_threads=8)
-    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77)
-    kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
-    assert np.all(s.errors == 0)
-    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
-    assert np.max(np.abs(kept - want["samples"])) < TOL
+    for placement in ("auto", "packed"):  # small ensemble: one wavefront per chain; packed: the throughput kernels
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement=placement)
+        if kind == "vmf" and k <= 16 and d <= 256:
+            assert s.mode == "fast"
+        kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
+        assert np.all(s.errors == 0)
+        assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+        assert np.max(np.abs(kept - want["samples"])) < TOL
     lp = pdf.log_prob(kept[:, -1])
     ref = tgt.log_prob(kept[:, -1])
     assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
