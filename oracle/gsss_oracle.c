@@ -22,6 +22,9 @@
  *   gor_step (shrink)           geosss/mcmc.py:382-401
  *   gor_step (reject)           geosss/mcmc.py:357-374
  *   gor_run                     geosss/mcmc.py:55-77 (the sampling loop, many chains)
+ *   gor_gradient                geosss/distributions.py:88-89, 159-160, 223-227, 277-278
+ *   gor_mh_run (RWMH)           geosss/mcmc.py:138-167 with AdaptiveStepsize :80-115
+ *   gor_mh_run (spherical HMC)  geosss/mcmc.py:236-318
  *
  * Parity pin: the reference's own tests hold no golden vectors for this path
  * (SURVEY.md §4); this oracle is pinned instead by the .npz files in tests/golden/, which
@@ -529,6 +532,202 @@ int gor_run(const gor_target *t, double *state, int64_t n_chains, int64_t n_step
         }
         if (pcg_state) gor_pcg_store(&pcg, pcg_state + 4 * c);
         free(scratch);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ RWMH and spherical HMC (mcmc.py:80-332) */
+
+#define GOR_RWMH 2
+#define GOR_HMC 3
+
+/* Distribution.gradient of the three target families.  BinghamFisher inherits Bingham.gradient in the
+ * reference (distributions.py:106-114 defines log_prob only), i.e. 2 A x without b: restated as is. */
+void gor_gradient(const gor_target *t, const double *x, double *g)
+{
+    int d = t->d;
+    if (t->kind == GOR_VMF_MIXTURE) {
+        /* distributions.py:223-227 : sum_k exp(p_k) mu_k / exp(logsumexp(p)) */
+        double *p = (double *)malloc(sizeof(double) * (size_t)t->k);
+        for (int k = 0; k < t->k; ++k) p[k] = gor_dot(x, t->mu + (size_t)k * d, d) - t->lognorm[k] + t->logw[k];
+        double den = exp(gor_logsumexp(p, t->k));
+        for (int i = 0; i < d; ++i) {
+            double acc = 0.0;
+            for (int k = 0; k < t->k; ++k) acc += exp(p[k]) * t->mu[(size_t)k * d + i];
+            g[i] = acc / den;
+        }
+        free(p);
+    } else if (t->kind == GOR_BINGHAM) {
+        for (int i = 0; i < d; ++i) g[i] = 2.0 * gor_dot(t->A + (size_t)i * d, x, d); /* distributions.py:88-89 : 2 * A @ x */
+    } else {
+        gor_find_nearest(t->knots, t->k, d, x, g);                                    /* distributions.py:277-278 */
+        for (int i = 0; i < d; ++i) g[i] *= t->kappa;
+    }
+}
+
+/* numpy's random_standard_gamma for shape > 1 (Marsaglia-Tsang, numpy/random/src/distributions/distributions.c):
+ * what Generator.gamma(d/2) in MetropolisHastings.propose (mcmc.py:143) draws from. */
+static double gor_npy_standard_gamma(gor_pcg64 *g, double shape)
+{
+    double b = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * b);
+    for (;;) {
+        double X, V;
+        do {
+            X = gor_npy_standard_normal(g);
+            V = 1.0 + c * X;
+        } while (V <= 0.0);
+        V = V * V * V;
+        double U = gor_npy_double(g);
+        if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return b * V;
+        if (log(U) < 0.5 * X * X + b * (1.0 - V + log(V))) return b * V;
+    }
+}
+void gor_npy_gamma_fill(uint64_t *pcg, double shape, int64_t n, double *out)
+{
+    gor_pcg64 g;
+    gor_pcg_load(&g, pcg);
+    for (int64_t i = 0; i < n; ++i) out[i] = gor_npy_standard_gamma(&g, shape);
+    gor_pcg_store(&g, pcg);
+}
+
+/* r = sqrt(2 * gamma(d / 2)) of mcmc.py:143.  numpy stream: numpy's own gamma; replay: the recorded gamma
+ * variate; Philox stream: the norm of d further standard normals (blocks 1 + nq ...), a chi_d variate like r */
+static double gor_draw_chi(gor_draws *g)
+{
+    int d = g->d;
+    if (g->pcg) return sqrt(2.0 * gor_npy_standard_gamma(g->pcg, 0.5 * (double)d));
+    if (g->replay) return sqrt(2.0 * gor_take(g));
+    uint32_t nq = (uint32_t)((d + 3) / 4);
+    double ss = 0.0;
+    for (int j = 0; 4 * j < d; ++j) {
+        uint32_t w[4];
+        double zz[4];
+        gor_stream_words(g->seed, g->chain, g->step, 1u + nq + (uint32_t)j, w);
+        gor_box_muller32(w[0], w[1], &zz[0], &zz[1]);
+        gor_box_muller32(w[2], w[3], &zz[2], &zz[3]);
+        for (int i = 0; i < 4 && 4 * j + i < d; ++i) ss += zz[i] * zz[i];
+    }
+    return sqrt(ss);
+}
+
+static double gor_draw_accept(gor_draws *g)
+{
+    if (g->pcg) return gor_npy_double(g->pcg);
+    if (g->replay) return gor_take(g);
+    double u[2];
+    gor_stream_block(g->seed, g->chain, g->step, 0u, u);
+    return u[0];
+}
+
+/* project(x, v) of mcmc.py:231-235 : x - v (v . x) */
+static void gor_project(double *x, const double *v, int d)
+{
+    double c = gor_dot(v, x, d);
+    for (int i = 0; i < d; ++i) x[i] -= v[i] * c;
+}
+
+/*
+ * n_steps transitions of MetropolisHastings (sampler = GOR_RWMH, mcmc.py:138-167) or SphericalHMC (GOR_HMC,
+ * mcmc.py:270-318) for n_chains independent chains.
+ *   state    [n_chains][d] in/out;  momenta [n_chains][d] in/out or NULL (HMC: the v half of the reference's state)
+ *   stepsize [n_chains] in/out: AdaptiveStepsize (mcmc.py:108-115) multiplies it by 1.02 / 0.98 after each of the
+ *            first `adapt_steps` steps of this call
+ *   n_accept [n_chains] ADDED to;  accept_trace / stepsize_trace [n_chains][n_steps] or NULL
+ * Draws per step in the reference's order: RWMH gamma(d/2), d normals, 1 uniform; HMC d normals, 1 uniform.
+ */
+int gor_mh_run(const gor_target *t, double *state, double *momenta, int64_t n_chains, int64_t n_steps, int64_t thin,
+               uint64_t seed, uint64_t chain_offset, uint64_t step_offset, int sampler, double *stepsize,
+               int64_t adapt_steps, int n_leapfrog, double *samples, int64_t *n_accept, int32_t *err,
+               const double *replay, int64_t replay_stride, int n_threads, uint64_t *pcg_state, uint8_t *accept_trace,
+               double *stepsize_trace)
+{
+    int d = t->d;
+    if (thin < 1) thin = 1;
+    int64_t n_keep = n_steps / thin;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (int64_t c = 0; c < n_chains; ++c) {
+        double *buf = (double *)malloc(sizeof(double) * (size_t)(6 * d));
+        double *z = buf, *y = buf + d, *xx = buf + 2 * d, *vv = buf + 3 * d, *gr = buf + 4 * d, *v = buf + 5 * d;
+        double *x = state + (size_t)c * d;
+        double eps = stepsize[c];
+        gor_draws g;
+        memset(&g, 0, sizeof(g));
+        g.d = d;
+        g.seed = seed;
+        g.chain = chain_offset + (uint64_t)c;
+        if (replay) {
+            g.replay = replay + (size_t)c * replay_stride;
+            g.replay_len = replay_stride;
+        }
+        gor_pcg64 pcg;
+        if (pcg_state) {
+            gor_pcg_load(&pcg, pcg_state + 4 * c);
+            g.pcg = &pcg;
+        }
+        if (momenta)
+            memcpy(v, momenta + (size_t)c * d, sizeof(double) * (size_t)d);
+        else
+            memset(v, 0, sizeof(double) * (size_t)d);
+        for (int64_t s = 0; s < n_steps; ++s) {
+            g.step = step_offset + (uint64_t)s;
+            int accepted;
+            if (sampler == GOR_RWMH) {
+                double r = gor_draw_chi(&g);                       /* mcmc.py:143 */
+                gor_draw_normals(&g, z);                           /* mcmc.py:144 */
+                for (int i = 0; i < d; ++i) y[i] = r * x[i] + eps * z[i];
+                gor_radial_projection(y, d, y);                    /* mcmc.py:145 */
+                double prob = gor_logprob(t, y) - gor_logprob(t, x); /* mcmc.py:152 */
+                accepted = log(gor_draw_accept(&g)) < prob;        /* mcmc.py:153 */
+                if (accepted) memcpy(x, y, sizeof(double) * (size_t)d);
+            } else {
+                gor_draw_normals(&g, z);                           /* mcmc.py:278 : v = project(normal, x) */
+                memcpy(v, z, sizeof(double) * (size_t)d);
+                gor_project(v, x, d);
+                double h0 = 0.5 * gor_dot(v, v, d) - gor_logprob(t, x); /* mcmc.py:285-286 */
+                memcpy(xx, x, sizeof(double) * (size_t)d);
+                memcpy(vv, v, sizeof(double) * (size_t)d);
+                gor_gradient(t, xx, gr);
+                gor_project(gr, xx, d);
+                for (int i = 0; i < d; ++i) vv[i] += 0.5 * eps * gr[i]; /* mcmc.py:301 */
+                for (int l = 0; l < n_leapfrog; ++l) {
+                    double norm = sqrt(gor_dot(vv, vv, d));
+                    double cs = cos(eps * norm), sn = sin(eps * norm);
+                    for (int i = 0; i < d; ++i) {
+                        double yi = xx[i];
+                        xx[i] = yi * cs + (vv[i] / norm) * sn;     /* mcmc.py:307 */
+                        vv[i] = vv[i] * cs - (yi * norm) * sn;     /* mcmc.py:308 */
+                    }
+                    gor_gradient(t, xx, gr);
+                    gor_project(gr, xx, d);
+                    double f = (l < n_leapfrog - 1) ? eps : 0.5 * eps; /* mcmc.py:310-313 */
+                    for (int i = 0; i < d; ++i) vv[i] += f * gr[i];
+                }
+                gor_radial_projection(xx, d, xx);                  /* mcmc.py:315 */
+                double h1 = 0.5 * gor_dot(vv, vv, d) - gor_logprob(t, xx);
+                accepted = log(gor_draw_accept(&g)) < h0 - h1;     /* mcmc.py:318-319 */
+                if (accepted) {
+                    memcpy(x, xx, sizeof(double) * (size_t)d);
+                    memcpy(v, vv, sizeof(double) * (size_t)d);
+                }
+            }
+            if (n_accept) n_accept[c] += accepted;
+            if (s < adapt_steps) eps *= accepted ? 1.02 : 0.98;    /* mcmc.py:113-115 */
+            if (accept_trace) accept_trace[c * n_steps + s] = (uint8_t)accepted;
+            if (stepsize_trace) stepsize_trace[c * n_steps + s] = eps;
+            if (samples && (s + 1) % thin == 0)
+                memcpy(samples + ((size_t)c * n_keep + ((s + 1) / thin - 1)) * d, x, sizeof(double) * (size_t)d);
+            if (g.exhausted) {
+                if (err) err[c] |= GOR_ERR_REPLAY_EXHAUSTED;
+                break;
+            }
+        }
+        stepsize[c] = eps;
+        if (momenta) memcpy(momenta + (size_t)c * d, v, sizeof(double) * (size_t)d);
+        if (pcg_state) gor_pcg_store(&pcg, pcg_state + 4 * c);
+        free(buf);
     }
     return 0;
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "libgsss_oracle.so")
 
 VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
-SHRINK, REJECT = 0, 1
+SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
 ERR_MAX_TRIES, ERR_NONFINITE, ERR_REPLAY_EXHAUSTED = 1, 2, 4
 
 
@@ -168,6 +168,59 @@ def run(target, state, n_steps, seed=0, chain_offset=0, step_offset=0, sampler=S
                   C.c_int64(stride), _p(thr), C.c_int(n_threads), _p(pcg))
     return dict(state=state[0] if single else state, samples=samples, n_reject=n_reject, n_tries=n_tries, err=err,
                 threshold=thr, pcg=pcg)
+
+
+def gradient(target, x):
+    x = _f64(x)
+    g = np.empty_like(x)
+    lib().gor_gradient(C.byref(target.c), _p(x), _p(g))
+    return g
+
+
+def npy_gamma(pcg_words, shape, n):
+    """n variates of numpy's Generator.gamma(shape) from the restated stream."""
+    w = np.array(pcg_words, dtype=np.uint64).reshape(4).copy()
+    out = np.empty(n)
+    lib().gor_npy_gamma_fill(_p(w), C.c_double(shape), C.c_int64(n), _p(out))
+    return out, w
+
+
+def mh_run(target, state, n_steps, sampler=RWMH, stepsize=0.1, adapt_steps=0, n_leapfrog=10, seed=0, chain_offset=0,
+           step_offset=0, thin=1, keep_samples=True, replay=None, n_threads=1, numpy_seed=None, momenta=None,
+           trace=False):
+    """MetropolisHastings / SphericalHMC (geosss/mcmc.py:118-332) for every row of `state`.
+    Returns dict(state, momenta, samples, n_accept, stepsize, err, accept (trace), stepsize_trace, pcg)."""
+    state = np.array(state, dtype=np.float64, order="C", copy=True)
+    single = state.ndim == 1
+    if single:
+        state = state[None]
+    n, d = state.shape
+    assert d == target.d
+    n_keep = n_steps // thin
+    samples = np.empty((n, n_keep, d)) if keep_samples else None
+    n_accept = np.zeros(n, dtype=np.int64)
+    err = np.zeros(n, dtype=np.int32)
+    eps = np.broadcast_to(np.asarray(stepsize, dtype=np.float64), (n,)).copy()
+    mom = np.zeros((n, d)) if momenta is None else np.array(momenta, dtype=np.float64, order="C", copy=True).reshape(n, d)
+    stride = 0
+    if replay is not None:
+        replay = _f64(replay)
+        if replay.ndim == 1:
+            replay = replay[None]
+        assert replay.shape[0] == n
+        stride = replay.shape[1]
+    pcg = None
+    if numpy_seed is not None:
+        pcg = pcg64_words(numpy_seed if isinstance(numpy_seed, (list, tuple)) else [numpy_seed])
+        assert len(pcg) == n
+    acc = np.zeros((n, n_steps), dtype=np.uint8) if trace else None
+    eps_tr = np.zeros((n, n_steps)) if trace else None
+    lib().gor_mh_run(C.byref(target.c), _p(state), _p(mom), C.c_int64(n), C.c_int64(n_steps), C.c_int64(thin),
+                     C.c_uint64(seed), C.c_uint64(chain_offset), C.c_uint64(step_offset), C.c_int(sampler), _p(eps),
+                     C.c_int64(adapt_steps), C.c_int(n_leapfrog), _p(samples), _p(n_accept), _p(err), _p(replay),
+                     C.c_int64(stride), C.c_int(n_threads), _p(pcg), _p(acc), _p(eps_tr))
+    return dict(state=state[0] if single else state, momenta=mom[0] if single else mom, samples=samples,
+                n_accept=n_accept, stepsize=eps, err=err, accept=acc, stepsize_trace=eps_tr, pcg=pcg)
 
 
 def sample_sphere(seed, n, d, chain_offset=0):

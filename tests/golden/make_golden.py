@@ -63,6 +63,11 @@ class RecordingRNG:
         self.draws.append(u)
         return lo + (hi - lo) * u
 
+    def gamma(self, shape):
+        v = self.g.gamma(shape)
+        self.draws.append(v)
+        return v
+
 
 class LoggingTarget:
     """Wraps pdf.log_prob so every evaluation made by the sampler is logged."""
@@ -386,8 +391,62 @@ def make_diagnostics():
     save("diagnostics_kat.npz", **arrays)
 
 
+def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10):
+    """One chain of the reference's MetropolisHastings (mcmc.py:118-176) or SphericalHMC (:236-332) with every draw
+    recorded in consumption order (RWMH: gamma(d/2), d normals, 1 uniform; HMC: d normals, 1 uniform), the state,
+    the accept flag and the adapted stepsize after every step (AdaptiveStepsize adapts during the first `burnin`
+    steps, as Sampler.sample(n, burnin) arranges, mcmc.py:169-176)."""
+    def build():
+        if kind == "rwmh":
+            return gs.MetropolisHastings(pdf, np.array(x0, dtype=float), seed, stepsize=stepsize)
+        return gs.SphericalHMC(pdf, np.array(x0, dtype=float), seed, stepsize=stepsize, n_steps=n_leapfrog)
+    d = len(x0)
+    s0 = build()
+    s0.reset(burnin)
+    truth = [np.copy(next(s0))[:d] for _ in range(n_steps)]
+    s = build()
+    s.reset(burnin)
+    s.rng = RecordingRNG(seed)
+    states, accept, eps, offs = [np.array(x0, dtype=float)], [], [], [0]
+    for _ in range(n_steps):
+        n0 = s.n_accept
+        y = np.copy(next(s))
+        states.append(y[:d])
+        accept.append(s.n_accept - n0)
+        eps.append(s.stepsize)
+        offs.append(len(s.rng.draws))
+    states = np.array(states)
+    assert np.array_equal(states[1:], np.array(truth)), "proxy RNG changed the chain"
+    out = dict(states=states, accept=np.array(accept, dtype=np.int8), stepsize_trace=np.array(eps),
+               draws=np.array(s.rng.draws), step_draw_offset=np.array(offs, dtype=np.int64),
+               n_accept=np.int64(s.n_accept), seed=np.int64(seed), burnin=np.int64(burnin),
+               stepsize0=np.float64(stepsize), n_leapfrog=np.int64(n_leapfrog), sampler=np.array(kind))
+    if kind == "hmc":
+        out["momenta"] = np.array(s.state[d:])
+    return out
+
+
+def make_mh():
+    """RWMH / spherical HMC reference chains + gradient known answers."""
+    rng = np.random.default_rng(77)
+    plan = [("vmfmix_readme", 600, 200, 0.1), ("bingham_d10_vmax30", 500, 150, 0.1), ("curve_d10_kappa800", 300, 100, 0.1),
+            ("vmfmix_d10_k5_kappa100", 300, 100, 0.1), ("bingham_d5_dense", 300, 100, 0.1), ("binghamfisher_d5", 300, 100, 0.05),
+            ("curve_d50_kappa800", 120, 40, 0.05)]
+    for name, n, burn, eps in plan:
+        pdf, x0, seed, _ = cases()[name]
+        for kind in ("rwmh", "hmc"):
+            rec = record_mh(kind, pdf, x0, seed + 1000, n, burn, eps)
+            print(f"{kind}_{name}: {n} steps, accept rate {rec['n_accept'] / n:.3f}, final stepsize {rec['stepsize_trace'][-1]:.4f}")
+            d = len(x0)
+            X = rsphere.radial_projection(rng.standard_normal((64, d)))
+            grad = np.array([pdf.gradient(x) for x in X])
+            save(f"mh_{kind}_{name}.npz", x0=np.array(x0), grad_X=X, grad=grad, **flat_params(target_params(pdf)), **rec)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics"]
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh"]
+    if "mh" in what:
+        make_mh()
     if "timing" in what:
         make_timing()
     if "diagnostics" in what:
