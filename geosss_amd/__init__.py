@@ -10,11 +10,12 @@ from . import _lib, diagnostics, sphere
 from .diagnostics import IAT, acf, acf_fft, distance, n_eff
 from .distributions import (Bingham, BinghamFisher, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
                             brownian_curve, random_bingham)
-from .mcmc import RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, determine_burnin
+from .mcmc import (MetropolisHastings, RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, SphericalHMC,
+                   determine_burnin)
 from .sphere import sample_sphere, sample_sphere_device
 from .utils import SamplerLauncher, count_calls, counter
 
 __all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
-           "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
+           "MetropolisHastings", "SphericalHMC", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
            "sphere", "diagnostics", "IAT", "acf", "acf_fft", "distance", "n_eff"]

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSSS_HIP_LIB") or os.path.join(_HERE, "libgsss_hip.so")  # env: side-by-side A/B builds
 
 VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
-SHRINK, REJECT = 0, 1
+SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
 MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
@@ -32,7 +32,8 @@ class RunArgs(C.Structure):
                 ("sampler", C.c_int32), ("mode", C.c_int32), ("max_tries", C.c_int32), ("variant", C.c_int32),
                 ("rng_state_dev", C.c_void_p), ("samples_chain_rows", C.c_int64), ("placement", C.c_int32),
                 ("stats_lags", C.c_int32), ("stats_dev", C.c_void_p), ("stats_dirs_dev", C.c_void_p),
-                ("stats_modes", C.c_int32), ("reserved", C.c_int32)]
+                ("stats_modes", C.c_int32), ("n_leapfrog", C.c_int32), ("stepsize_dev", C.c_void_p),
+                ("n_accept_dev", C.c_void_p), ("momenta_dev", C.c_void_p), ("adapt_steps", C.c_int64)]
 
 
 # symbol -> (restype, argtypes); must list every function include/gsss.h declares

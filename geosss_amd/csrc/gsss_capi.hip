@@ -10,6 +10,7 @@
 
 #include "gsss_fast.h"
 #include "gsss_launch.h"
+#include "gsss_mh.h"
 
 namespace gsss {
 
@@ -427,8 +428,14 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("need n_chains >= 0, n_steps >= 0, thin >= 1, max_tries >= 1");
         return GSSS_E_INVALID;
     }
-    if (a->sampler != GSSS_SHRINK && a->sampler != GSSS_REJECT) {
+    const bool mh = a->sampler == GSSS_RWMH || a->sampler == GSSS_HMC;
+    if (a->sampler != GSSS_SHRINK && a->sampler != GSSS_REJECT && !mh) {
         set_error("unknown sampler %d", a->sampler);
+        return GSSS_E_INVALID;
+    }
+    if (mh && (a->mode != GSSS_MODE_EXACT || !a->stepsize_dev || a->adapt_steps < 0 || a->stats_dev ||
+               (a->sampler == GSSS_HMC && a->n_leapfrog < 1))) {
+        set_error("GSSS_RWMH / GSSS_HMC need GSSS_MODE_EXACT, stepsize_dev, adapt_steps >= 0, no stats_dev (HMC: n_leapfrog >= 1)");
         return GSSS_E_INVALID;
     }
     if (a->mode != GSSS_MODE_EXACT && a->mode != GSSS_MODE_FAST) {
@@ -531,6 +538,25 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
             return GSSS_E_INVALID;
         }
         return fast_dispatch(t->tb, rb, replay, nullptr, st);
+    }
+    if (mh) {
+        if (a->rng_state_dev && a->sampler == GSSS_RWMH && t->tb.d < 3) {
+            set_error("numpy's gamma(1) is an exponential ziggurat, not restated: RWMH on numpy's stream needs d >= 3");
+            return GSSS_E_UNSUPPORTED;
+        }
+        MhBlock mb;
+        mb.stepsize = a->stepsize_dev;
+        mb.n_accept = a->n_accept_dev;
+        mb.momenta = a->sampler == GSSS_HMC ? a->momenta_dev : nullptr;
+        mb.adapt_steps = a->adapt_steps;
+        mb.n_leapfrog = a->n_leapfrog;
+        switch (t->tb.kind) {
+        case GSSS_VMF_MIXTURE: return launch_mh<VmfMixture>(vec, draws, a->sampler, t->tb, rb, mb, st);
+        case GSSS_BINGHAM: return launch_mh<Bingham>(vec, draws, a->sampler, t->tb, rb, mb, st);
+        case GSSS_CURVE_VMF: return launch_mh<CurveVmf>(vec, draws, a->sampler, t->tb, rb, mb, st);
+        }
+        set_error("corrupt target");
+        return GSSS_E_INVALID;
     }
     switch (t->tb.kind) {
     case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, draws, t->tb, rb, st);

@@ -303,8 +303,8 @@ struct PhiloxDraws {
         u0 = u53(w[0], w[1]);
         u1 = u53(w[2], w[3]);
     }
-    // block 1+q carries the normals 4q .. 4q+3
-    __device__ __forceinline__ void normals(double (&z)[V::N], int g) const
+    // block 1+q carries the normals 4q .. 4q+3 (blk_off: a second set of d normals further down the stream)
+    __device__ __forceinline__ void normals(double (&z)[V::N], int g, uint32_t blk_off = 0u) const
     {
 #pragma unroll
         for (int iq = 0; iq < (V::N + 3) / 4; ++iq) {
@@ -312,7 +312,7 @@ struct PhiloxDraws {
             double zz[4] = {0.0, 0.0, 0.0, 0.0};
             if (c0 < d) {
                 uint32_t w[4];
-                words(1u + (uint32_t)(c0 >> 2), w);
+                words(1u + blk_off + (uint32_t)(c0 >> 2), w);
                 box_muller32(w[0], w[1], zz[0], zz[1]);
                 if (c0 + 2 < d) box_muller32(w[2], w[3], zz[2], zz[3]);
             }
@@ -331,6 +331,22 @@ struct PhiloxDraws {
         if (tt & 1) return cached;
         double u0;
         block(1u + (uint32_t)((d + 3) >> 2) + (uint32_t)(tt >> 1), u0, cached);
+        return u0;
+    }
+    // RWMH (mcmc.py:143): r = sqrt(2 gamma(d/2)) is a chi_d variate -- here the norm of d further normals
+    __device__ __forceinline__ double chi(int g) const
+    {
+        double z2[V::N];
+        normals(z2, g, (uint32_t)((d + 3) >> 2));
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) s = fma(z2[i], z2[i], s);
+        return sqrt(V::reduce(s));
+    }
+    __device__ __forceinline__ double accept_uniform() const
+    {
+        double u0, u1;
+        block(0u, u0, u1);
         return u0;
     }
 };
@@ -384,6 +400,8 @@ struct ReplayDraws {
         u_theta0 = need_theta0 ? take() : 0.0;
     }
     __device__ __forceinline__ double next_try() { return take(); }
+    __device__ __forceinline__ double chi(int) { return sqrt(2.0 * take()); }  // the recorded gamma(d/2) variate
+    __device__ __forceinline__ double accept_uniform() { return take(); }
 };
 
 // numpy's own stream: PCG64 (XSL-RR 128/64) + Generator.random / uniform / standard_normal, so that
@@ -502,6 +520,24 @@ struct NumpyDraws {
         u_theta0 = need_theta0 ? next_double() : 0.0;
     }
     __device__ __forceinline__ double next_try() { return next_double(); }
+    // Generator.gamma(shape), shape > 1: numpy's random_standard_gamma (Marsaglia-Tsang on the ziggurat normals)
+    __device__ double standard_gamma(double shape)
+    {
+        const double b = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * b);
+        for (;;) {
+            double X, Vv;
+            do {
+                X = standard_normal();
+                Vv = 1.0 + c * X;
+            } while (Vv <= 0.0);
+            Vv = Vv * Vv * Vv;
+            const double U = next_double();
+            if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return b * Vv;
+            if (log(U) < 0.5 * X * X + b * (1.0 - Vv + log(Vv))) return b * Vv;
+        }
+    }
+    __device__ __forceinline__ double chi(int) { return sqrt(2.0 * standard_gamma(0.5 * (double)d)); }  // mcmc.py:143
+    __device__ __forceinline__ double accept_uniform() { return next_double(); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -550,6 +586,24 @@ struct VmfMixture {
         double s = 0.0;
         for (int k = 0; k < K; ++k) s += fm::exp_fast(comp_logp(y, g, k) - amax);
         return amax + fm::log_fast(s);
+    }
+    // distributions.py:223-227 : sum_k exp(p_k) mu_k / exp(logsumexp(p))  (the softmax-weighted mean of the mu_k)
+    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
+    {
+        double amax = -INFINITY;
+        for (int k = 0; k < K; ++k) amax = fmax(amax, comp_logp(y, g, k));
+        double den = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) out[i] = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double w = fm::exp_fast(comp_logp(y, g, k) - amax);
+            den += w;
+            const double *m = mu + (size_t)k * V::DPAD;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) out[i] = fma(w, m[V::comp(g, i)], out[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) out[i] /= den;
     }
     static constexpr int kScratchPerChain = 0;
 };
@@ -610,6 +664,36 @@ struct Bingham {
             return V::reduce(s);
         }
     }
+    // distributions.py:88-89 : 2 A y (also what BinghamFisher inherits in the reference: its b does not enter)
+    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double *scratch, double (&out)[V::N]) const
+    {
+        if constexpr (V::L == 1) {
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) {
+                double xa = 0.0;
+#pragma unroll
+                for (int i = 0; i < V::N; ++i) xa = fma(A[j * V::DPAD + i], y[i], xa);
+                out[j] = 2.0 * xa;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) scratch[V::comp(g, i)] = y[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) out[j] = 0.0;
+            for (int i = 0; i < d; ++i) {  // (A y)_j = sum_i A_ij y_i for the lane's own components j (A symmetric)
+                const double yi = scratch[i];
+#pragma unroll
+                for (int j = 0; j < V::N; ++j) out[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], out[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < V::N; ++j) out[j] *= 2.0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     static constexpr int kScratchPerChain = (V::L == 1) ? 0 : V::DPAD + 1;
 };
 
@@ -666,6 +750,37 @@ struct CurveVmf {
             ay = by;
         }
         return kappa * best_dot;
+    }
+    // distributions.py:277-278 : kappa * find_nearest(y)
+    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
+    {
+        double best = INFINITY;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) out[i] = 0.0;
+        double ay = kdot(y, g, 0);
+        for (int s = 0; s + 1 < K; ++s) {
+            const double by = kdot(y, g, s + 1);
+            const double theta = seg[4 * s], ct = seg[4 * s + 1], st = seg[4 * s + 2], den = seg[4 * s + 3];
+            double t = atan2(by - ay * ct, ay * st);
+            t = fmin(fmax(t, 0.0), theta);
+            const double sa = sin(theta - t), sb = sin(t);
+            const double *a = knots + (size_t)s * V::DPAD, *b = a + V::DPAD;
+            double near[V::N], xy = 0.0;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) {
+                const int c = V::comp(g, i);
+                near[i] = (sa * a[c] + sb * b[c]) / den;
+                xy = fma(y[i], near[i], xy);
+            }
+            xy = V::reduce(xy);
+            const double dist = acos(fmin(fmax(xy, -1.0), 1.0));
+            if (dist < best) {
+                best = dist;
+#pragma unroll
+                for (int i = 0; i < V::N; ++i) out[i] = kappa * near[i];
+            }
+            ay = by;
+        }
     }
     static constexpr int kScratchPerChain = 0;
 };

@@ -33,7 +33,8 @@ import torch
 from . import _lib
 from .sphere import _device_index, current_stream_ptr
 
-__all__ = ["determine_burnin", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler"]
+__all__ = ["determine_burnin", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler", "MetropolisHastings",
+           "SphericalHMC"]
 
 _MODES = {"exact": _lib.MODE_EXACT, "fast": _lib.MODE_FAST, "auto": None}
 _MAX_STEPS_PER_LAUNCH = 4096
@@ -354,12 +355,16 @@ class RejectionSphericalSliceSampler:
             if replay is not None:
                 raise ValueError("replay and rng='numpy' are mutually exclusive")
             a.rng_state_dev = self._rng_state.data_ptr()
+        self._launch_extra(a, int(n_steps))
         if self._stats is not None and stats:
             a.stats_dev = self._stats["acc"].data_ptr()
             a.stats_dirs_dev = self._stats["dirs"].data_ptr()
             a.stats_lags, a.stats_modes = self._stats["lags"], self._stats["modes"]
         _lib.check(self._lib.gsss_run(self._target_dev.handle, C.byref(a), self._stream()))
         self._step += int(n_steps)
+
+    def _launch_extra(self, a, n_steps):
+        """Hook for samplers with further launch arguments."""
 
     def advance(self, n_steps, *, thin=None, out=None, replay=None, chain_major=False, row0=0, keep=True):
         """Advance every chain by n_steps transitions on the GPU (asynchronously).
@@ -480,3 +485,128 @@ class ShrinkageSphericalSliceSampler(RejectionSphericalSliceSampler):
     """Geodesic shrinkage slice sampler (mcmc.py:377-401), many chains."""
 
     _sampler = _lib.SHRINK
+
+
+class MetropolisHastings(RejectionSphericalSliceSampler):
+    """Random-walk Metropolis-Hastings on the sphere for many chains (geosss/mcmc.py:118-176): project into ambient
+    space, perturb, project back; `stepsize` adapts during burn-in (AdaptiveStepsize, mcmc.py:80-115), each chain its
+    own.  Same constructor and attributes as the reference: `.stepsize`, `.n_accept`, `.reset(burnin)`."""
+
+    _sampler = _lib.RWMH
+    _calls_per_step = 2  # log_prob(proposal) and log_prob(state), mcmc.py:152
+
+    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, **kwargs):
+        if kwargs.get("mode", "exact") not in ("exact", "auto"):
+            raise ValueError("RWMH / HMC evaluate log_prob from the point itself: mode='exact'")
+        kwargs["mode"] = "exact"
+        super().__init__(distribution, initial_state, seed, **kwargs)
+        if not float(stepsize) > 0.0:
+            raise AssertionError("stepsize must be positive")  # mcmc.py:98
+        self._stepsize = torch.full((self.n_chains,), float(stepsize), dtype=torch.float64, device=self._tdev)
+        self._n_accept = torch.zeros(self.n_chains, dtype=torch.int64, device=self._tdev)
+        self.reset(0)
+
+    def reset(self, burnin):
+        """AdaptiveStepsize.reset (mcmc.py:100-103): the next `burnin` transitions adapt the stepsize."""
+        self._counter = 0
+        self._burnin = int(burnin)
+
+    def _launch_extra(self, a, n_steps):
+        a.stepsize_dev = self._stepsize.data_ptr()
+        a.n_accept_dev = self._n_accept.data_ptr()
+        a.adapt_steps = max(0, min(n_steps, self._burnin - self._counter))
+        a.n_reject_dev = None
+        a.n_tries_dev = None
+        self._counter += n_steps
+
+    @property
+    def stepsize(self):
+        e = self._stepsize.cpu().numpy()
+        return float(e[0]) if self._single else e
+
+    @stepsize.setter
+    def stepsize(self, value):
+        self._stepsize.copy_(torch.as_tensor(np.broadcast_to(np.asarray(value, dtype=np.float64), (self.n_chains,)).copy()))
+
+    @property
+    def n_accept(self):
+        """Accepted proposals, total over chains (mcmc.py:136); per chain: n_accept_per_chain."""
+        return int(self._n_accept.sum().item())
+
+    @property
+    def n_accept_per_chain(self):
+        return self._n_accept.cpu().numpy()
+
+    def _account_calls(self, n_steps):
+        fn = getattr(type(self.target), "log_prob", None)
+        if fn is not None and hasattr(fn, "num_calls"):
+            fn.num_calls += self._calls_per_step * n_steps * self.n_chains
+
+    def sample(self, n_samples, burnin=0, return_all_samples=False, *, thin=1, as_tensor=False):
+        """mcmc.py:169-176: the stepsize adapts during the first `burnin` transitions, then Sampler.sample."""
+        self.reset(determine_burnin(n_samples, burnin))
+        return super().sample(n_samples, burnin, return_all_samples, thin=thin, as_tensor=as_tensor)
+
+    def enable_stats(self, *a, **k):
+        raise ValueError("running statistics are accumulated by the slice-sampler kernels")
+
+    def state_dict(self):
+        d = super().state_dict()
+        d.update(stepsize=self._stepsize.cpu().numpy(), n_accept=self.n_accept_per_chain, counter=self._counter,
+                 burnin=self._burnin)
+        return d
+
+    def load_state_dict(self, d):
+        super().load_state_dict(d)
+        self._stepsize.copy_(torch.from_numpy(np.asarray(d["stepsize"], dtype=np.float64)))
+        self._n_accept.copy_(torch.from_numpy(np.asarray(d["n_accept"], dtype=np.int64)))
+        self._counter, self._burnin = int(d["counter"]), int(d["burnin"])
+
+
+class SphericalHMC(MetropolisHastings):
+    """Spherical Hamiltonian Monte Carlo for many chains (geosss/mcmc.py:236-332): `n_steps` leapfrog steps of size
+    `stepsize` along great circles, Metropolis correction with the Hamiltonian; needs the target's gradient (device
+    functors for the three target families; BinghamFisher's is 2 A x as in the reference, distributions.py:88-114)."""
+
+    _sampler = _lib.HMC
+
+    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-3, n_steps=10, **kwargs):
+        super().__init__(distribution, initial_state, seed, stepsize=stepsize, **kwargs)
+        self.n_steps = int(n_steps)
+        if self.n_steps < 1:
+            raise ValueError("n_steps must be >= 1")
+        self._momenta = torch.zeros((self.d, self.n_chains), dtype=torch.float64, device=self._tdev)  # mcmc.py:262
+
+    def _launch_extra(self, a, n_steps):
+        super()._launch_extra(a, n_steps)
+        a.n_leapfrog = self.n_steps
+        a.momenta_dev = self._momenta.data_ptr()
+
+    @property
+    def momenta(self):
+        v = self._momenta.T.contiguous().cpu().numpy()
+        return v[0] if self._single else v
+
+    @property
+    def state(self):
+        """[x, v] stacked, as the reference keeps it (mcmc.py:262)."""
+        x = self.state_rows().cpu().numpy()
+        xv = np.hstack([x, self._momenta.T.cpu().numpy()])
+        return xv[0] if self._single else xv
+
+    @state.setter
+    def state(self, value):
+        value = np.asarray(value, dtype=np.float64)
+        if value.shape[-1] == 2 * self.d:
+            x, v = value[..., : self.d], value[..., self.d:]
+            self._momenta.copy_(torch.from_numpy(np.ascontiguousarray(np.atleast_2d(v).T)))
+            value = x
+        n_old = self.n_chains
+        self._set_state(value)
+        if self.n_chains != n_old:
+            raise ValueError("the number of chains is fixed at construction")
+
+    def sample(self, n_samples, burnin=0, return_momenta=False, return_all_samples=False, *, thin=1, as_tensor=False):
+        if return_momenta:
+            raise NotImplementedError("momenta are not retained per draw; `sampler.momenta` holds the current ones")
+        return super().sample(n_samples, burnin, return_all_samples, thin=thin, as_tensor=as_tensor)

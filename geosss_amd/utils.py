@@ -1,7 +1,7 @@
-"""Launcher + call counter with the reference's names (geosss/utils.py:137-232), restricted to
-the two samplers this package implements."""
+"""Launcher + call counter with the reference's names (geosss/utils.py:137-232): the two geodesic slice samplers
+and the two baselines the paper compares them with (RWMH, spherical HMC)."""
 from .distributions import counted
-from .mcmc import RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler
+from .mcmc import MetropolisHastings, RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, SphericalHMC
 
 count_calls = counted
 
@@ -40,11 +40,23 @@ class SamplerLauncher:
         self.ssss = ShrinkageSphericalSliceSampler(self.pdf, self.initial, self.seed, **self.sampler_kwargs)
         return self.ssss.sample(self.n_samples, burnin=self.burnin)
 
+    def run_rwmh(self):
+        kw = {k: v for k, v in self.sampler_kwargs.items() if k not in ("mode", "screen", "placement")}
+        self.rwmh = MetropolisHastings(self.pdf, self.initial, self.seed, stepsize=1e-1, **kw)  # utils.py:210-214
+        return self.rwmh.sample(self.n_samples, burnin=self.burnin)
+
+    def run_hmc(self):
+        kw = {k: v for k, v in self.sampler_kwargs.items() if k not in ("mode", "screen", "placement")}
+        self.hmc = SphericalHMC(self.pdf, self.initial, self.seed, stepsize=1e-1, **kw)          # utils.py:216-220
+        return self.hmc.sample(self.n_samples, burnin=self.burnin)
+
     def run(self, method):
         if method == "sss-reject":
             return self.run_sss_reject()
         if method == "sss-shrink":
             return self.run_sss_shrink()
-        if method in ("rwmh", "hmc"):
-            raise ValueError(f"method {method} is outside this package (only the geodesic slice samplers are built)")
-        raise ValueError(f"method {method} not known")
+        if method == "rwmh":
+            return self.run_rwmh()
+        if method == "hmc":
+            return self.run_hmc()
+        raise ValueError(f"method {method} not known")  # utils.py:232

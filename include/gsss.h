@@ -42,6 +42,8 @@ extern "C" {
 /* samplers (geosss/mcmc.py) */
 #define GSSS_SHRINK 0 /* ShrinkageSphericalSliceSampler.__next__  :382-401 */
 #define GSSS_REJECT 1 /* RejectionSphericalSliceSampler.__next__  :357-374 */
+#define GSSS_RWMH 2   /* MetropolisHastings.__next__ (random-walk MH)  :138-167, AdaptiveStepsize :80-115 */
+#define GSSS_HMC 3    /* SphericalHMC.__next__ (leapfrog on the sphere) :270-319 */
 
 /* arithmetic of the proposal evaluation */
 #define GSSS_MODE_EXACT 0 /* y = cos*x + sin*u formed, log_prob(y) evaluated from y op by op as the reference does */
@@ -153,7 +155,16 @@ typedef struct gsss_run_args {
                                   Lane-per-chain kernels only (d <= 10 exact, the lane fast kernels); GSSS_E_UNSUPPORTED otherwise */
     const double *stats_dirs_dev; /* [2 + stats_modes][d]: w, h, then the mode directions; required with stats_dev */
     int32_t stats_modes;       /* K >= 0 */
-    int32_t reserved;
+    int32_t n_leapfrog;        /* GSSS_HMC: leapfrog steps per proposal (SphericalHMC(n_steps=10), mcmc.py:243) */
+    /* GSSS_RWMH / GSSS_HMC (the baselines of the paper; GSSS_MODE_EXACT, any layout; n_tries / n_reject / stats unused): */
+    double *stepsize_dev;      /* [n_chains] in/out: proposal scale / leapfrog stepsize of every chain (mcmc.py:97, 133, 241) */
+    int64_t *n_accept_dev;     /* [n_chains] or NULL; accepted proposals are ADDED (MetropolisHastings.n_accept) */
+    double *momenta_dev;       /* GSSS_HMC: NULL or [d][n_chains] in/out, the momentum half of the reference's state (mcmc.py:262) */
+    int64_t adapt_steps;       /* the first adapt_steps steps of this call multiply the stepsize by 1.02 after an accepted and by
+                                  0.98 after a rejected proposal (AdaptiveStepsize.adapt_stepsize during burn-in, mcmc.py:108-115).
+                                  Draws per step, in the reference's order: RWMH gamma(d/2), d normals, one uniform; HMC d normals,
+                                  one uniform (replay_dev holds the gamma variate itself; the Philox stream uses the norm of d
+                                  further normals, the same chi_d law; rng_state_dev restates numpy's gamma) */
 } gsss_run_args;
 
 int gsss_abi_version(void);

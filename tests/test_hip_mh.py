@@ -1,0 +1,142 @@
+"""GPU parity of the paper's baselines -- MetropolisHastings (geosss/mcmc.py:118-176) and SphericalHMC (:236-332) --
+through the C ABI (GSSS_RWMH / GSSS_HMC) against the reference's recorded chains and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import product_target, variants_for
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("mh_") and f.endswith(".npz"))
+
+
+@pytest.fixture(scope="module")
+def gs():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import geosss_amd
+    geosss_amd._lib.require_device()
+    return geosss_amd
+
+
+def build(gs, z, x0, seed, **kw):
+    pdf = product_target(z)
+    if str(z["sampler"]) == "rwmh":
+        return gs.MetropolisHastings(pdf, x0, seed, stepsize=float(z["stepsize0"]), **kw)
+    return gs.SphericalHMC(pdf, x0, seed, stepsize=float(z["stepsize0"]), n_steps=int(z["n_leapfrog"]), **kw)
+
+
+def tol_for(z):  # see tests/test_oracle_mh.py: HMC trajectories amplify rounding
+    return 1e-9 if str(z["sampler"]) == "hmc" else 1e-10
+
+
+def _params():
+    out = []
+    for name in CASES:
+        d = int(golden(name + ".npz")["x0"].shape[0])
+        out += [(name, v) for v in variants_for(d, max_coop=1)]
+    return out
+
+
+@pytest.mark.parametrize("name,variant", _params())
+def test_replay_reproduces_reference_chain(gs, name, variant):
+    """The reference's recorded draws through the HIP kernel: every state, every accept decision, the adapted stepsize."""
+    z = golden(name + ".npz")
+    s = build(gs, z, z["x0"], 1, variant=variant)
+    n = len(z["states"]) - 1
+    s.reset(int(z["burnin"]))
+    kept = s.advance(n, thin=1, replay=z["draws"][None])
+    got = kept[:, :, 0].cpu().numpy()
+    assert s.errors[0] == 0
+    acc = np.any(got != np.vstack([z["x0"][None], got[:-1]]), axis=1)          # the state moved = accepted
+    assert np.array_equal(acc, z["accept"].astype(bool))
+    assert s.n_accept == int(z["n_accept"])
+    assert np.max(np.abs(got - z["states"][1:])) < tol_for(z)
+    assert abs(s.stepsize / z["stepsize_trace"][-1] - 1) < 1e-12
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_chain_from_seed(gs, name):
+    """Sampler(pdf, x0, seed).sample(n, burnin) from the seed alone on numpy's own stream (gamma, normal, uniform)."""
+    z = golden(name + ".npz")
+    s = build(gs, z, z["x0"], int(z["seed"]), rng="numpy")
+    n = len(z["states"]) - 1
+    s.reset(int(z["burnin"]))
+    got = s.advance(n, thin=1)[:, :, 0].cpu().numpy()
+    assert np.max(np.abs(got - z["states"][1:])) < tol_for(z)
+    assert s.n_accept == int(z["n_accept"])
+    if "momenta" in z.files:
+        assert np.max(np.abs(s.momenta - z["momenta"])) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["mh_rwmh_vmfmix_readme", "mh_hmc_vmfmix_readme", "mh_rwmh_bingham_d10_vmax30",
+                                  "mh_hmc_bingham_d10_vmax30", "mh_rwmh_curve_d10_kappa800", "mh_hmc_curve_d10_kappa800",
+                                  "mh_rwmh_curve_d50_kappa800", "mh_hmc_curve_d50_kappa800", "mh_hmc_bingham_d5_dense"])
+def test_philox_stream_matches_oracle(gs, oracle, name):
+    """Many chains on the library's counter-based stream: device = oracle (accept counts exactly, adapted stepsizes and
+    states to rounding), for any split of the steps over launches."""
+    z = golden(name + ".npz")
+    tgt = oracle.Target.from_fixture(z)
+    d = len(z["x0"])
+    hmc = str(z["sampler"]) == "hmc"
+    n_chains, n_steps, burn = (300, 30, 12) if d <= 10 else (64, 16, 6)
+    x0 = oracle.sample_sphere(4, n_chains, d, chain_offset=50)
+    want = oracle.mh_run(tgt, x0, n_steps, sampler=oracle.HMC if hmc else oracle.RWMH, stepsize=float(z["stepsize0"]),
+                         adapt_steps=burn, n_leapfrog=10, seed=31, chain_offset=50, step_offset=3, n_threads=8)
+    s = build(gs, z, x0, 31, chain_offset=50, step_offset=3)
+    s.reset(burn)
+    s.advance(7)
+    s.advance(n_steps - 7)
+    # chains whose trajectories passed within rounding of an accept threshold may legitimately differ: none here
+    assert np.array_equal(s.n_accept_per_chain, want["n_accept"])
+    assert np.max(np.abs(s.stepsize / want["stepsize"] - 1)) < 1e-12
+    assert np.max(np.abs(s.state[:, :d] - want["state"])) < (1e-8 if hmc else 1e-10)
+
+
+def test_sample_api_and_launcher(gs):
+    """Reference call shapes: sample(n, burnin) with stepsize adaptation during burn-in (mcmc.py:169-176), the [x, v]
+    state of SphericalHMC (mcmc.py:262), SamplerLauncher.run('rwmh' / 'hmc') (utils.py:210-232), call counters."""
+    z = golden("traj_bingham_d10_vmax30.npz")
+    pdf = product_target(z)
+    type(pdf).log_prob.reset_counters()
+    s = gs.MetropolisHastings(pdf, z["x0"], 5)
+    out = s.sample(200, burnin=0.2)
+    assert out.shape == (200, 10) and 0 < s.n_accept < 239 and isinstance(s.stepsize, float) and s.stepsize != 0.1
+    assert pdf.log_prob.num_calls == 2 * 239
+    e = s.stepsize
+    s.advance(10)                                       # after burn-in the stepsize stays put (detailed balance)
+    assert s.stepsize == e
+    h = gs.SphericalHMC(pdf, z["x0"], 5, stepsize=0.05, n_steps=7)
+    pos = h.sample(50, burnin=10)
+    assert pos.shape == (50, 10) and h.state.shape == (20,) and h.momenta.shape == (10,)
+    assert abs(np.dot(h.state[:10], h.state[10:])) < 1e-10     # momenta are tangent
+    many = gs.MetropolisHastings(pdf, gs.sample_sphere(9, 1000, seed=2), 6, stepsize=0.2)
+    X = many.sample(40, burnin=20)
+    assert X.shape == (1000, 40, 10) and many.stepsize.shape == (1000,) and np.ptp(many.stepsize) > 0
+    assert np.max(np.abs(np.linalg.norm(X, axis=-1) - 1)) < 1e-12
+    L = gs.SamplerLauncher(pdf, z["x0"], 30, burnin=0.2, seed=3)
+    assert L.run("rwmh").shape == (30, 10) and L.run("hmc").shape == (30, 10) and L.hmc.n_steps == 10
+    with pytest.raises(ValueError):
+        L.run("kent")
+    with pytest.raises(ValueError):
+        gs.MetropolisHastings(pdf, z["x0"], 1, mode="fast")
+
+
+def test_baselines_sample_the_target(gs):
+    """RWMH and HMC ensembles agree with the slice sampler on the Bingham target's second moments (the eigenbasis target
+    of scripts/bingham.py:131): three samplers, one distribution."""
+    z = golden("traj_bingham_d10_vmax30.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere(9, 20000, seed=8)
+    ref = gs.ShrinkageSphericalSliceSampler(pdf, x0, 1)
+    ref.advance(300)
+    m_ref = np.mean(ref.state ** 2, axis=0)
+    for cls, kw, steps in ((gs.MetropolisHastings, dict(stepsize=0.3), 3000), (gs.SphericalHMC, dict(stepsize=0.1), 400)):
+        s = cls(pdf, x0, 2, **kw)
+        s.reset(steps // 4)
+        s.advance(steps)
+        m = np.mean(s.state[:, :10] ** 2, axis=0)
+        assert np.max(np.abs(m - m_ref)) < 0.02, (cls.__name__, m, m_ref)
