@@ -280,3 +280,22 @@ def test_ess_at_full_ensemble_size_without_stored_draws(gs):
     assert 0.02 < rel < 0.06, rel                                    # IAT of the first coordinate ~ 30 steps
     occ = r["mode_occupancy"].mean(0).cpu().numpy()
     assert np.max(np.abs(occ - 1 / 3)) < 0.01
+
+
+def test_published_mode_occupancy_is_a_typical_chain(gs):
+    """scripts/visualize_mixture_vMF.ipynb:497-498 prints how many of the 10^6 draws of ONE geoSSS (shrink) chain fall to
+    each of the K = 5 modes of the d = 10, kappa = 100 mixture: [181891 184255 253442 173708 206704].  64 chains of the
+    same length here: every mode is visited a fifth of the time on average, and the published chain's deviations from
+    1/5 lie within the chain-to-chain spread (mode switching is slow, so single chains scatter by several per cent)."""
+    from conftest import golden
+    from helpers import product_target
+    pdf = product_target(golden("traj_vmfmix_d10_k5_kappa100.npz"))
+    paper = np.array([181891, 184255, 253442, 173708, 206704]) / 1e6
+    s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere(9, 64, seed=12), seed=99).enable_stats(lags=0)
+    s.advance(20_000)
+    s.advance(1_000_000, thin=10, keep=False)
+    occ = s.stats()["mode_occupancy"].cpu().numpy()            # (64, 5)
+    assert np.max(np.abs(occ.mean(0) - 0.2)) < 0.03
+    spread = occ.std(0)
+    assert np.all(spread > 0.01)                                # chains do differ: the published scatter is expected
+    assert np.max(np.abs(paper - 0.2) / spread) < 4.0, (paper, spread)
