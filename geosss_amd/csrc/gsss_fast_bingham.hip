@@ -1,5 +1,5 @@
 // GSSS_MODE_FAST instantiations for Bingham targets.
-#include "gsss_fast.h"
+#include "gsss_screen.h"
 
 namespace gsss {
 
@@ -9,8 +9,13 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
 {
 #define GSSS_CASE(D)                                               \
     if (tb.d == D) {                                               \
-        if (probe) GSSS_PROBE(true, "fast_kernel<%d, FastBingham<%d>>", D, D); \
-        return do_fast<D, FastBingham<D>>(tb, rb, replay, st);     \
+        const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr; \
+        if (probe) {                                               \
+            if (rb.screen) GSSS_PROBE(true, "screened_kernel<%d, ScreenBingham<%d>>", D, D); \
+            GSSS_PROBE(true, "fast_kernel<%d, FastBingham<%d>>", D, D); \
+        }                                                          \
+        if (!screen) return do_fast<D, FastBingham<D>>(tb, rb, replay, st); \
+        return replay ? do_screened_run<D, ScreenBingham<D>, true>(tb, rb, st) : do_screened_run<D, ScreenBingham<D>, false>(tb, rb, st); \
     }
     GSSS_FAST_BINGHAM_DIMS(GSSS_CASE)
 #undef GSSS_CASE

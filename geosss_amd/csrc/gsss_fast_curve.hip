@@ -1,4 +1,5 @@
 // GSSS_MODE_FAST instantiations for curve-vMF targets (10 knots, the reference's brownian_curve default).
+#include "gsss_screen.h"
 #include "gsss_spec64.h"
 
 namespace gsss {
@@ -10,8 +11,13 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, Fa
 {
 #define GSSS_CASE(D)                                                \
     if (tb.d == D && tb.k == 10) {                                  \
-        if (probe) GSSS_PROBE(true, "fast_kernel<%d, FastCurve<%d, 10>>", D, D); \
-        return do_fast<D, FastCurve<D, 10>>(tb, rb, replay, st);    \
+        const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr; \
+        if (probe) {                                                \
+            if (rb.screen) GSSS_PROBE(true, "screened_kernel<%d, ScreenCurve<%d, 10>>", D, D); \
+            GSSS_PROBE(true, "fast_kernel<%d, FastCurve<%d, 10>>", D, D); \
+        }                                                           \
+        if (!screen) return do_fast<D, FastCurve<D, 10>>(tb, rb, replay, st); \
+        return replay ? do_screened_run<D, ScreenCurve<D, 10>, true>(tb, rb, st) : do_screened_run<D, ScreenCurve<D, 10>, false>(tb, rb, st); \
     }
     GSSS_FAST_CURVE_DIMS(GSSS_CASE)
 #undef GSSS_CASE

@@ -147,6 +147,145 @@ struct ScreenVmf : FastVmf<D, KC> {
     __device__ __forceinline__ void keep_set(Coef &, double) const {}
 };
 
+// Bingham / BinghamFisher: log-density q(theta) = c^2 qxx + c s qxu + s^2 quu + c bx + s bu (distributions.py:86, :113-114),
+// accepted iff q(theta) > thr = q(0) + log U.  With c^2 + s^2 = 1 the threshold is folded into the quadratic terms, so the
+// screen evaluates g = c^2 (qxx - thr) + c s qxu + s^2 (quu - thr) + c bx + s bu against 0 +- margin.
+template <int D>
+struct ScreenBingham : FastBingham<D> {
+    using Base = FastBingham<D>;
+    using Coef = typename Base::Coef;
+    static constexpr int kKeepWords = 0;
+    static constexpr int kCoef32Floats = 6;
+    static constexpr bool kCarry = false;
+    __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
+    {
+        (void)this->make(cf, x, u, 0.0, true);
+    }
+    __device__ __forceinline__ bool make32(const Coef &cf, double u_thr, float (&q)[kCoef32Floats]) const
+    {
+        const double lvl0 = cf.qxx + cf.bx;
+        const double thr = lvl0 + fm::log_fast(u_thr);  // mcmc.py:389
+        q[0] = (float)(cf.qxx - thr);
+        q[1] = (float)cf.qxu;
+        q[2] = (float)(cf.quu - thr);
+        q[3] = (float)cf.bx;
+        q[4] = (float)cf.bu;
+        const float sum = fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]) + fabsf(q[3]) + fabsf(q[4]);
+        // every term carries at most two trigonometric factors (2 eps), its coefficient's rounding and the fma roundings
+        float margin = 1.25f * sum * (2.0f * kSinCosErr32 + 6.0f * kUnit32) + 1.0e-30f;
+        if (!(u_thr > 1e-290) || !(margin < 1.0e30f)) margin = INFINITY;
+        q[5] = margin;
+        return lvl0 > -INFINITY && lvl0 < INFINITY;
+    }
+    __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const
+    {
+        const float g = fmaf(c, fmaf(c, q[0], fmaf(s, q[1], q[3])), s * fmaf(s, q[2], q[4]));
+        return g < -q[5] ? -1 : (g > q[5] ? 1 : 0);
+    }
+    __device__ __forceinline__ double threshold(Coef &cf, const double (&x)[D], const double (&u)[D], double u_thr) const
+    {
+        return this->make(cf, x, u, 0.0, true) + fm::log_fast(u_thr);
+    }
+    __device__ __forceinline__ double level_exact(const Coef &cf, double c, double s) const { return this->level(cf, c, s); }
+};
+
+// curve-vMF: level = kappa * max_g clip(y . nearest point of segment g) (FastCurve).  In units of the dot product the
+// screen compares  max_g xy_g - thr / kappa  with 0 +- margin.  y . nearest is a Lipschitz function of (a_g.y, a_{g+1}.y)
+// with constant <= 3 / sin(theta_g) (interior branch: |P y| / sin; end points: a.y itself), whichever branch the
+// single-precision evaluation takes, so margin = (3 delta + arithmetic) / min_g sin(theta_g), delta = error of a.y.
+template <int D, int NK>
+struct ScreenCurve : FastCurve<D, NK> {
+    using Base = FastCurve<D, NK>;
+    using Coef = typename Base::Coef;
+    static constexpr int kKeepWords = 0;
+    static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
+    static constexpr bool kCarry = false;
+    float seg32[(NK - 1) * 3];  // cos, sin, 1 / (sin + 1e-10) per segment
+    float inv_sin_min;
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        Base::stage(lds, tb);
+        __syncthreads();
+        float m = 0.0f;
+#pragma unroll
+        for (int g = 0; g + 1 < NK; ++g) {
+            seg32[3 * g] = (float)this->seg[4 * g];
+            seg32[3 * g + 1] = (float)this->seg[4 * g + 1];
+            seg32[3 * g + 2] = (float)this->seg[4 * g + 2];
+            m = fmaxf(m, fabsf(seg32[3 * g + 2]));
+        }
+        inv_sin_min = m;
+    }
+    __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            double ax = 0.0, au = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double kij = this->knots[i * D + j];
+                ax = fma(kij, x[j], ax);
+                au = fma(kij, u[j], au);
+            }
+            cf.ax[i] = ax;
+            cf.au[i] = au;
+        }
+    }
+    // max over the segments of the clipped y . nearest, single precision
+    __device__ __forceinline__ float best32(const float (&q)[kCoef32Floats], float c, float s) const
+    {
+        float best = -INFINITY;
+        float ay = fmaf(c, q[0], s * q[NK]);
+#pragma unroll
+        for (int g = 0; g + 1 < NK; ++g) {
+            const float by = fmaf(c, q[g + 1], s * q[NK + g + 1]);
+            const float ct = seg32[3 * g], st = seg32[3 * g + 1], rden = seg32[3 * g + 2];
+            const float A = ay * st;
+            const float B = fmaf(-ay, ct, by);
+            const float h2 = fmaf(A, A, B * B);
+            const float rh = h2 > 0.0f ? __builtin_amdgcn_rsqf(h2) : 0.0f;
+            const bool at_a = B < 0.0f || (B == 0.0f && A >= 0.0f);
+            const bool at_b = A * rh < ct;
+            const float num = at_a ? st * ay : (at_b ? st * by : h2 * rh);
+            best = fmaxf(best, fminf(fmaxf(num * rden, -1.0f), 1.0f));
+            ay = by;
+        }
+        return best;
+    }
+    __device__ __forceinline__ bool make32(const Coef &cf, double u_thr, float (&q)[kCoef32Floats]) const
+    {
+        float b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            q[i] = (float)cf.ax[i];
+            q[NK + i] = (float)cf.au[i];
+            b = fmaxf(b, fabsf(q[i]) + fabsf(q[NK + i]));
+        }
+        // error of a.y: (|a.x| + |a.u|) (eps + 2^-24) + the fma roundings
+        const float delta = b * (kSinCosErr32 + 3.0f * kUnit32);
+        // one evaluation: 3 delta Lipschitz + ~16 roundings of values <= 2, all over sin(theta_g); v_rsq_f32 relative 2^-22
+        const float e_eval = (3.0f * delta + 40.0f * kUnit32) * inv_sin_min * 1.05f;
+        // thr / kappa = level32(x) / kappa + log(U) / kappa: the level of x is evaluated by the same routine at theta = 0
+        const float lvl0 = best32(q, 1.0f, 0.0f);
+        const double tau = (double)lvl0 + fm::log_fast(u_thr) / this->kappa;
+        q[2 * NK] = (float)tau;
+        float margin = 1.25f * (2.0f * e_eval + kUnit32 * (fabsf(q[2 * NK]) + 1.0f));
+        if (!(u_thr > 1e-290) || !(margin < 0.25f)) margin = INFINITY;
+        q[2 * NK + 1] = margin;
+        return lvl0 >= -1.0f && lvl0 <= 1.0f;  // (NaN fails)
+    }
+    __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const
+    {
+        const float g = best32(q, c, s) - q[2 * NK];
+        return g < -q[2 * NK + 1] ? -1 : (g > q[2 * NK + 1] ? 1 : 0);
+    }
+    __device__ __forceinline__ double threshold(Coef &cf, const double (&x)[D], const double (&u)[D], double u_thr) const
+    {
+        return this->make(cf, x, u, 0.0, true) + fm::log_fast(u_thr);
+    }
+    __device__ __forceinline__ double level_exact(const Coef &cf, double c, double s) const { return this->level(cf, c, s); }
+};
+
 template <int D, class TP>
 struct ScreenChain {
     static constexpr int kQ = TP::kCoef32Floats + (TP::kCoef32Floats & 1);  // padded to whole 64-bit words
@@ -165,7 +304,7 @@ struct ScreenChain {
 template <int D, class TP>
 __host__ __device__ constexpr bool screen_parks()
 {
-    return (size_t)ScreenChain<D, TP>::kWords * kBlock * sizeof(double) <= 72 * 1024;
+    return (size_t)ScreenChain<D, TP>::kWords * kBlock * sizeof(double) <= 78 * 1024;  // two workgroups per CU (160 KB)
 }
 template <int D, class TP, bool REPLAY>
 __host__ __device__ constexpr size_t screen_lds_doubles()

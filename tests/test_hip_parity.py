@@ -626,7 +626,9 @@ def test_cooperative_fast_resume(gs, name):
 
 
 SCREEN_CASES = [("vmfmix_readme", 200_000, 60), ("vmfmix_k10_kappa500", 100_000, 40), ("vmfmix_d10_k5_kappa100", 50_000, 40),
-                ("vmfmix_d4_k4_weighted", 50_000, 40)]
+                ("vmfmix_d4_k4_weighted", 50_000, 40), ("bingham_d10_vmax30", 100_000, 60), ("bingham_d5_dense", 100_000, 60),
+                ("binghamfisher_d5", 100_000, 60), ("binghamfisher_d6", 50_000, 40), ("curve_d3_kappa300", 50_000, 40),
+                ("curve_d10_kappa800", 50_000, 40), ("curve_d10_kappa500", 50_000, 40), ("curve_d24_kappa800", 20_000, 30)]
 
 
 @pytest.mark.parametrize("name,n_chains,n_steps", SCREEN_CASES)
