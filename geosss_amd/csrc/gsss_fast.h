@@ -248,15 +248,19 @@ struct FastCurve {
     };
     static constexpr int kCoefWords = 2 * NK;
     __host__ __device__ static size_t lds_doubles() { return (size_t)NK * D + 4 * (size_t)(NK - 1); }
+    int nseg;  // segments of the target's curve: k - 1 <= NK - 1 (a curve of fewer knots runs the NK kernel: the surplus
+               // knot rows are zeros and their segments never take part in the maximum)
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         kappa = tb.kappa;
-        for (int i = threadIdx.x; i < NK * D; i += kBlock) lds[i] = tb.blob[i];
+        nseg = tb.k - 1;
+        for (int i = threadIdx.x; i < NK * D; i += kBlock) lds[i] = i < tb.k * D ? tb.blob[i] : 0.0;
         double *sg = lds + NK * D;
         for (int i = threadIdx.x; i < NK - 1; i += kBlock) {  // blob: theta, cos, sin, sin + 1e-10
-            sg[4 * i + 0] = tb.blob[(size_t)NK * D + 4 * i + 1];
-            sg[4 * i + 1] = tb.blob[(size_t)NK * D + 4 * i + 2];
-            sg[4 * i + 2] = 1.0 / tb.blob[(size_t)NK * D + 4 * i + 3];
+            const bool real = i < tb.k - 1;
+            sg[4 * i + 0] = real ? tb.blob[(size_t)tb.k * D + 4 * i + 1] : 1.0;
+            sg[4 * i + 1] = real ? tb.blob[(size_t)tb.k * D + 4 * i + 2] : 0.0;
+            sg[4 * i + 2] = real ? 1.0 / tb.blob[(size_t)tb.k * D + 4 * i + 3] : 0.0;
             sg[4 * i + 3] = 0.0;
         }
         knots = lds;
@@ -289,7 +293,7 @@ struct FastCurve {
             const double num = at_a ? st * ay : (at_b ? st * by : inner);
             const double xy = num * rden;
             const double xc = fmin(fmax(xy, -1.0), 1.0);
-            if (xc > best) {
+            if (g < nseg && xc > best) {
                 best = xc;
                 best_dot = xy;
             }
@@ -747,20 +751,25 @@ struct CoopCurve {
     Scalar sc;
     const double *rows;  // LDS [NK][DPAD]
     __host__ __device__ static size_t lds_doubles() { return (size_t)NK * V::DPAD + 4 * (size_t)(NK - 1); }
+    int nseg;  // k - 1 segments, k <= NK knots (surplus rows zero, surplus segments out of the maximum)
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
-        lds_fill(lds, NK, V::DPAD, tb.blob, tb.d);
+        nseg = tb.k - 1;
+        lds_fill(lds, tb.k, V::DPAD, tb.blob, tb.d);
+        for (int i = threadIdx.x + tb.k * V::DPAD; i < NK * V::DPAD; i += kBlock) lds[i] = 0.0;
         double *sg = lds + (size_t)NK * V::DPAD;
         for (int i = threadIdx.x; i < NK - 1; i += kBlock) {
-            sg[4 * i + 0] = tb.blob[(size_t)NK * tb.d + 4 * i + 1];
-            sg[4 * i + 1] = tb.blob[(size_t)NK * tb.d + 4 * i + 2];
-            sg[4 * i + 2] = 1.0 / tb.blob[(size_t)NK * tb.d + 4 * i + 3];
+            const bool real = i < tb.k - 1;
+            sg[4 * i + 0] = real ? tb.blob[(size_t)tb.k * tb.d + 4 * i + 1] : 1.0;
+            sg[4 * i + 1] = real ? tb.blob[(size_t)tb.k * tb.d + 4 * i + 2] : 0.0;
+            sg[4 * i + 2] = real ? 1.0 / tb.blob[(size_t)tb.k * tb.d + 4 * i + 3] : 0.0;
             sg[4 * i + 3] = 0.0;
         }
         rows = lds;
         sc.knots = lds;
         sc.seg = sg;
         sc.kappa = tb.kappa;
+        sc.nseg = tb.k - 1;
     }
     // Lane g of a group evaluates segment g (lanes >= NK-1 sit out); an xor-butterfly then picks the
     // first segment of maximal clipped y.near -- the same choice as the sequential scan.
@@ -801,7 +810,7 @@ struct CoopCurve {
         const bool at_b = A * rh < m.ct;
         const double num = at_a ? m.st * ay : (at_b ? m.st * by : inner);
         double xy = num * m.rden;
-        double xc = g < NK - 1 ? fmin(fmax(xy, -1.0), 1.0) : -INFINITY;
+        double xc = g < nseg ? fmin(fmax(xy, -1.0), 1.0) : -INFINITY;
         int idx = g;
         // (xc, idx) is totally ordered (larger xc first, then smaller idx): the winner of a row of 16 lanes
         // does not depend on the order of the pairwise steps; the segments live in lanes 0 .. NK-2 of row 0

@@ -9,8 +9,9 @@ namespace gsss {
 
 int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
 {
+    // lane-per-chain kernels: the listed dimensions, any curve of 2 .. 10 knots (built for 10; FastCurve pads)
 #define GSSS_CASE(D)                                                \
-    if (tb.d == D && tb.k == 10) {                                  \
+    if (tb.d == D && tb.k >= 2 && tb.k <= 10) {                     \
         const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr; \
         if (probe) {                                                \
             if (rb.screen) GSSS_PROBE(true, "screened_kernel<%d, ScreenCurve<%d, 10>>", D, D); \
@@ -26,12 +27,14 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, Fa
         if (probe) GSSS_PROBE(false, "curve64_kernel<%d>", tb.k <= 11 ? 12 : 20);
         return tb.k <= 11 ? do_curve64<12>(tb, rb, replay, st) : do_curve64<20>(tb, rb, replay, st);
     }
-    // other large d: lanes cooperate on one chain
-    if (tb.k == 10 && tb.d > 24 && tb.d <= 512) {
-        if (probe)
-            GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopCurve<10>>", tb.d <= 64 ? 16 : 64, tb.d <= 256 ? 4 : 8);
-        if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopCurve<CoopVec<16, 4>, 10>>(tb, rb, replay, st);
-        if (tb.d <= 256) return do_coopfast<CoopVec<64, 4>, CoopCurve<CoopVec<64, 4>, 10>>(tb, rb, replay, st);
+    // every other d <= 64 (and 11 .. 16 knots at the lane dimensions): 16 lanes cooperate on one chain
+    if (tb.d >= 3 && tb.d <= 64 && tb.k >= 2 && tb.k <= 16) {
+        if (probe) GSSS_PROBE(false, "coopfast_kernel<CoopVec<16, 4>, CoopCurve<%d>>", tb.k <= 10 ? 10 : 16);
+        if (tb.k <= 10) return do_coopfast<CoopVec<16, 4>, CoopCurve<CoopVec<16, 4>, 10>>(tb, rb, replay, st);
+        return do_coopfast<CoopVec<16, 4>, CoopCurve<CoopVec<16, 4>, 16>>(tb, rb, replay, st);
+    }
+    if (tb.k >= 2 && tb.k <= 10 && tb.d > 256 && tb.d <= 512) {
+        if (probe) GSSS_PROBE(false, "coopfast_kernel<CoopVec<64, 8>, CoopCurve<10>>");
         return do_coopfast<CoopVec<64, 8>, CoopCurve<CoopVec<64, 8>, 10>>(tb, rb, replay, st);
     }
     if (!probe) set_error("fast mode is not built for a curve-vMF target with d=%d, %d knots", tb.d, tb.k);

@@ -212,7 +212,7 @@ struct ScreenCurve : FastCurve<D, NK> {
             seg32[3 * g] = (float)this->seg[4 * g];
             seg32[3 * g + 1] = (float)this->seg[4 * g + 1];
             seg32[3 * g + 2] = (float)this->seg[4 * g + 2];
-            m = fmaxf(m, fabsf(seg32[3 * g + 2]));
+            if (g < this->nseg) m = fmaxf(m, fabsf(seg32[3 * g + 2]));
         }
         inv_sin_min = m;
     }
@@ -247,7 +247,7 @@ struct ScreenCurve : FastCurve<D, NK> {
             const bool at_a = B < 0.0f || (B == 0.0f && A >= 0.0f);
             const bool at_b = A * rh < ct;
             const float num = at_a ? st * ay : (at_b ? st * by : h2 * rh);
-            best = fmaxf(best, fminf(fmaxf(num * rden, -1.0f), 1.0f));
+            if (g < this->nseg) best = fmaxf(best, fminf(fmaxf(num * rden, -1.0f), 1.0f));
             ay = by;
         }
         return best;

@@ -54,7 +54,7 @@ def fast_supported(z, prefix="target_"):
         return d in FAST_BINGHAM or 10 < d <= 128  # cooperative fast kernels
     if kind == "curve_vmf":
         k, d = z[prefix + "knots"].shape
-        return (d, k) in FAST_CURVE or (k == 10 and 24 < d <= 512)  # cooperative fast kernels
+        return (3 <= d <= 64 and k <= 16) or (64 < d <= 256 and k <= 17) or (256 < d <= 512 and k <= 10)
     return False
 
 

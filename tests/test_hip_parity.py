@@ -257,6 +257,7 @@ SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16
          ("curve", 9, 10), ("curve", 15, 10), ("curve", 18, 10), ("curve", 21, 10), ("bingham", 7, 0), ("bingham", 9, 0),
          ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10),
          # any K <= 16 at any d: component buckets with exact padding (MixtureModel takes any K, distributions.py:209-227)
+         ("curve", 9, 4), ("curve", 10, 12), ("curve", 7, 10), ("curve", 30, 16), ("curve", 50, 6), ("curve", 100, 15), ("curve", 3, 2),
          ("vmf", 3, 7), ("vmf", 6, 3), ("vmf", 8, 13), ("vmf", 9, 16), ("vmf", 4, 1), ("vmf", 7, 4), ("vmf", 30, 7), ("vmf", 100, 12)]
 
 
@@ -282,7 +283,7 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
     want = oracle.run(tgt, x0, n_steps, seed=77, n_threads=8)
     for placement in ("auto", "packed"):  # small ensemble: one wavefront per chain; packed: the throughput kernels
         s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement=placement)
-        if kind == "vmf" and k <= 16 and d <= 256:
+        if (kind == "vmf" and k <= 16 and d <= 256) or (kind == "curve" and d <= 256):
             assert s.mode == "fast"
         kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
         assert np.all(s.errors == 0)
