@@ -200,20 +200,21 @@ struct ScreenCurve : FastCurve<D, NK> {
     static constexpr int kKeepWords = 0;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
     static constexpr bool kCarry = false;
-    float seg32[(NK - 1) * 3];  // cos, sin, 1 / (sin + 1e-10) per segment
+    const float4 *seg32;  // LDS [NK-1]: cos, sin, 1 / (sin + 1e-10) per segment in single precision (read as one broadcast b128)
     float inv_sin_min;
+    __host__ __device__ static size_t lds_doubles() { return Base::lds_doubles() + 2 * (size_t)(NK - 1); }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         Base::stage(lds, tb);
         __syncthreads();
+        float4 *s32 = reinterpret_cast<float4 *>(lds + Base::lds_doubles());
+        for (int g = threadIdx.x; g < NK - 1; g += kBlock)
+            s32[g] = make_float4((float)this->seg[4 * g], (float)this->seg[4 * g + 1], (float)this->seg[4 * g + 2], 0.0f);
+        seg32 = s32;
         float m = 0.0f;
 #pragma unroll
-        for (int g = 0; g + 1 < NK; ++g) {
-            seg32[3 * g] = (float)this->seg[4 * g];
-            seg32[3 * g + 1] = (float)this->seg[4 * g + 1];
-            seg32[3 * g + 2] = (float)this->seg[4 * g + 2];
-            if (g < this->nseg) m = fmaxf(m, fabsf(seg32[3 * g + 2]));
-        }
+        for (int g = 0; g + 1 < NK; ++g)
+            if (g < this->nseg) m = fmaxf(m, fabsf((float)this->seg[4 * g + 2]));
         inv_sin_min = m;
     }
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
@@ -229,6 +230,8 @@ struct ScreenCurve : FastCurve<D, NK> {
             }
             cf.ax[i] = ax;
             cf.au[i] = au;
+            // one knot at a time: left alone the scheduler hoists all NK * D loads of the knots (2 NK D registers)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // max over the segments of the clipped y . nearest, single precision
@@ -239,7 +242,8 @@ struct ScreenCurve : FastCurve<D, NK> {
 #pragma unroll
         for (int g = 0; g + 1 < NK; ++g) {
             const float by = fmaf(c, q[g + 1], s * q[NK + g + 1]);
-            const float ct = seg32[3 * g], st = seg32[3 * g + 1], rden = seg32[3 * g + 2];
+            const float4 sg = seg32[g];
+            const float ct = sg.x, st = sg.y, rden = sg.z;
             const float A = ay * st;
             const float B = fmaf(-ay, ct, by);
             const float h2 = fmaf(A, A, B * B);
@@ -322,6 +326,7 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
     b = __uint_as_float((uint32_t)(o >> 32));
 }
 
+// (measured: asking for two wavefronts per SIMD at d = 10 makes the curve kernel spill 73 registers: 45 -> 64 ms)
 template <int D, class TP, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlock a)
 {
