@@ -175,6 +175,25 @@ __device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, double &z
     z1 = r * s;
 }
 
+// the same pair with the table-driven log and sincos of gsss_math.h (throughput kernels; ~1 ulp from the above)
+__device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, const fm::Tables &t, double &z0, double &z1)
+{
+    const double r = sqrt(-2.0 * fm::log_word_tab(wr, t));
+    double s, c;
+    fm::sincos_word_tab(wa, t, s, c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// LDS doubles a kernel sets aside for fm::Tables (16-byte aligned inside the dynamic LDS block)
+constexpr int kTabLds = fm::kTableDoubles + 2;
+__device__ __forceinline__ fm::Tables stage_tables(double *lds_after_params)
+{
+    double *buf = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(lds_after_params) + 15) & ~(uintptr_t)15);
+    for (int i = threadIdx.x; i < 64 + fm::kLogTableN; i += kBlock) fm::table_entry(buf, i);
+    return fm::Tables{buf, buf + 128};
+}
+
 constexpr uint64_t kInitStep = 0xFFFFFFFFFFFFull;  // reserved step id: initial states (gsss_sample_sphere)
 
 // ------------------------------------------------------------------------------------------
@@ -265,8 +284,9 @@ __device__ __forceinline__ double vdot(const double (&a)[V::N], const double (&b
 // ------------------------------------------------------------------------------------------
 // Draw sources
 // ------------------------------------------------------------------------------------------
-template <class V>
+template <class V, bool TAB = false>
 struct PhiloxDraws {
+    fm::Tables tab;  // TAB: Box-Muller on the table-driven log / sincos (set by the kernel)
     static constexpr bool kReplay = false;
     static constexpr int kLdsDoubles = 0;
     __device__ __forceinline__ void stage(double *) {}
@@ -313,8 +333,13 @@ struct PhiloxDraws {
             if (c0 < d) {
                 uint32_t w[4];
                 words(1u + blk_off + (uint32_t)(c0 >> 2), w);
-                box_muller32(w[0], w[1], zz[0], zz[1]);
-                if (c0 + 2 < d) box_muller32(w[2], w[3], zz[2], zz[3]);
+                if constexpr (TAB) {
+                    box_muller32(w[0], w[1], tab, zz[0], zz[1]);
+                    if (c0 + 2 < d) box_muller32(w[2], w[3], tab, zz[2], zz[3]);
+                } else {
+                    box_muller32(w[0], w[1], zz[0], zz[1]);
+                    if (c0 + 2 < d) box_muller32(w[2], w[3], zz[2], zz[3]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)

@@ -373,7 +373,7 @@ __host__ __device__ constexpr int fast_chains_per_block()
 template <int D, class TP, bool REPLAY>
 __host__ __device__ constexpr size_t fast_lds_doubles()
 {
-    return TP::lds_doubles() +
+    return TP::lds_doubles() + kTabLds +
            (fast_parks<D, TP>() ? (size_t)(REPLAY ? FastChain<D, TP>::kWords : FastChain<D, TP>::kWordsNoReplay) * kBlock
                                 : 0);
 }
@@ -386,8 +386,9 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
+    const fm::Tables tab = stage_tables(lds + TP::lds_doubles());
     // word w of this lane's parked chain lives at park[w * kBlock]: conflict-free across lanes
-    unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles()) + threadIdx.x;
+    unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles() + kTabLds) + threadIdx.x;
     __syncthreads();
 
     const int32_t n = (int32_t)a.n_chains;
@@ -410,7 +411,8 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
 
     auto chain_id = [&]() { return slot ? id1 : id0; };
     auto philox = [&]() {
-        PhiloxDraws<V> dr;
+        PhiloxDraws<V, true> dr;
+        dr.tab = tab;
         dr.init(a, chain_id(), D);
         dr.begin_step(a.step_offset + (uint64_t)cur.steps_done);
         return dr;
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             u_thr = replay_take();
             u_th0 = shrink ? replay_take() : 0.0;
         } else {
-            const PhiloxDraws<V> dr = philox();
+            const PhiloxDraws<V, true> dr = philox();
             dr.normals(cur.u, 0);
             dr.block(0u, u_thr, u_th0);
         }
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
                 const double uu = REPLAY ? replay_take() : u_pair[h];
                 const double theta = fma(cur.hi - cur.lo, uu, cur.lo);  // mcmc.py:395
                 ++cur.t;
-                fm::sincos_small(theta, sn, cs);
+                fm::sincos_tab(theta, tab, sn, cs);
                 lvl = tp.level(cur.cf, cs, sn, cur.thr);
                 accepted = lvl > cur.thr;                               // mcmc.py:397
                 if (!accepted && shrink) {                              // mcmc.py:400
@@ -1249,8 +1251,9 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
+    const fm::Tables tab = stage_tables(lds + TP::lds_doubles());
     NumpyDraws<V> nd;
-    if (NUMPY) nd.stage(lds + TP::lds_doubles());
+    if (NUMPY) nd.stage(lds + TP::lds_doubles() + kTabLds);
     __syncthreads();
 
     const int lane = threadIdx.x % 64;
@@ -1265,7 +1268,8 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
     double x[D];  // wave-uniform values: every lane holds the chain's state
 #pragma unroll
     for (int j = 0; j < D; ++j) x[j] = a.state[(size_t)j * n + c];
-    PhiloxDraws<V> dr;
+    PhiloxDraws<V, true> dr;
+    dr.tab = tab;
     if (NUMPY)
         nd.init(a, c, D);
     else
@@ -1307,7 +1311,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                     wa = g;
                 }
             }
-            box_muller32(wr, wa, z0, z1);
+            box_muller32(wr, wa, tab, z0, z1);
 #pragma unroll
             for (int p = 0; p < kPairs; ++p) {
                 u[2 * p] = lane_broadcast(z0, p);
@@ -1388,7 +1392,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                 }
             }
             double sn, cs;
-            fm::sincos_small(my_theta, sn, cs);
+            fm::sincos_tab(my_theta, tab, sn, cs);
             const double my_lvl = tp.level(cf, cs, sn, thr);
             const bool ok = lane < kSpecTries && t_base + lane < a.max_tries && my_lvl > thr;  // mcmc.py:397
             const unsigned long long mask = __ballot(ok);
@@ -1446,7 +1450,7 @@ int do_wave(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
     static_assert(16 % kSpecTries == 0 && (D + 1) / 2 <= 8 && (D + 3) / 4 <= 55, "Box-Muller pairs must fit the lanes reserved for them");
     const bool numpy = rb.rng_state != nullptr;
-    const size_t lds = (TP::lds_doubles() + (numpy ? NumpyDraws<LaneVec<D>>::kLdsDoubles : 0)) * sizeof(double);
+    const size_t lds = (TP::lds_doubles() + kTabLds + (numpy ? NumpyDraws<LaneVec<D>>::kLdsDoubles : 0)) * sizeof(double);
     auto kern = numpy ? wave_kernel<D, TP, true, false> : wave_kernel<D, TP, false, false>;
     if (rb.stats != nullptr) kern = numpy ? wave_kernel<D, TP, true, true> : wave_kernel<D, TP, false, true>;
     if (lds > 48 * 1024) {

@@ -186,5 +186,94 @@ GSSS_HD double log_fast(double x)
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// ------------------------------------------------------------------------------------------
+// Table-driven variants for the throughput kernels: 64 points of the circle and 93 points of log on
+// [sqrt(1/2), sqrt(2)] (2.5 KB, staged in LDS by the kernel) cut the polynomial degrees: sincos 21 instead of 38
+// instructions, the logarithm of a 32-bit uniform 20 instead of 35 (no division).  Accuracy ~1 ulp like the polynomial
+// versions (tests/test_math.py measures both).  Table entries: sc[j] = (sin, cos)(2 pi j / 64),
+// lg[j - 90] = (log m_j, 1 / m_j), m_j = j / 128, j = 90 .. 182.
+// ------------------------------------------------------------------------------------------
+struct Tables {
+    const double *sc;  // [64][2]
+    const double *lg;  // [93][2]
+};
+constexpr int kLogTableLo = 90, kLogTableN = 93;
+constexpr int kTableDoubles = 2 * 64 + 2 * kLogTableN;
+
+// fills `buf` (kTableDoubles doubles); entry i of the combined list is computed by one caller (i = 0 .. 64 + 129 - 1)
+GSSS_HD void table_entry(double *buf, int i)
+{
+    if (i < 64) {
+        double sn, cs;
+        sincos_2pi((double)i * (1.0 / 64.0), sn, cs);
+        buf[2 * i] = sn;
+        buf[2 * i + 1] = cs;
+    } else if (i < 64 + kLogTableN) {
+        const int j = i - 64;
+        const double m = (double)(j + kLogTableLo) * (1.0 / 128.0);
+        buf[128 + 2 * j] = log_fast(m);  // (exactly 0 at m = 1)
+        buf[128 + 2 * j + 1] = 1.0 / m;
+    }
+}
+
+// sin and cos of r (|r| <= pi/64 + rounding) around the table point (sa, ca): sin(a + r), cos(a + r)
+GSSS_HD void sincos_around(double sa, double ca, double r, double &so, double &co)
+{
+    const double z = r * r;
+    double p = GSSS_FMAK(z, 2.75573192239858906526e-06, -1.98412698412698412698e-04);   // r^9/9!, -r^7/7!
+    p = GSSS_FMAK(p, z, 8.33333333333333333333e-03);
+    p = GSSS_FMAK(p, z, -1.66666666666666666667e-01);
+    const double sr = fma(r * z, p, r);                                                 // sin r
+    double q = GSSS_FMAK(z, 2.48015873015873015873e-05, -1.38888888888888888889e-03);   // z^4/8!, -z^3/6!
+    q = GSSS_FMAK(q, z, 4.16666666666666666667e-02);
+    q = GSSS_FMAK(q, z, -0.5);
+    const double cm1 = z * q;                                                           // cos r - 1
+    so = sa + fma(ca, sr, sa * cm1);
+    co = ca + fma(-sa, sr, ca * cm1);
+}
+
+// sin and cos of x, |x| <= 8
+GSSS_HD void sincos_tab(double x, const Tables &t, double &so, double &co)
+{
+    const double k = rint(x * 1.01859163578813017e+01);            // 32 / pi
+    double r = fma(-k, 9.81747704208828508854e-02, x);                            // pi / 32, high 33 bits: k * it is exact
+    r = fma(-k, 3.79818781656637015582e-12, r);                                   // pi / 32 - high part
+    const int j = (int)k & 63;
+    sincos_around(t.sc[2 * j], t.sc[2 * j + 1], r, so, co);
+}
+
+// sin and cos of 2 pi (w / 2^32) for a 32-bit word w: the nearest table point and an exact signed remainder
+GSSS_HD void sincos_word_tab(uint32_t w, const Tables &t, double &so, double &co)
+{
+    const uint32_t j = (w + (1u << 25)) >> 26;                      // 0 .. 64 (64 wraps to 0)
+    const int32_t rem = (int32_t)(w - (j << 26));                   // in [-2^25, 2^25)
+    const double r = (double)rem * 1.46291807926715968105e-09;      // 2 pi / 2^32
+    const int jj = (int)(j & 63u);
+    sincos_around(t.sc[2 * jj], t.sc[2 * jj + 1], r, so, co);
+}
+
+// log((w + 1) / 2^32) for a 32-bit word w (the radius uniform of a Box-Muller pair, in (0, 1])
+GSSS_HD double log_word_tab(uint32_t w, const Tables &t)
+{
+    const double v = (double)w + 1.0;                               // 1 .. 2^32, exact
+    int e;
+    double m = frexp(v, &e);                                        // [0.5, 1)
+    if (m < 7.07106781186547524401e-01) {                           // -> [sqrt(1/2), sqrt(2)): log m is small where log v is
+        m *= 2.0;
+        e -= 1;
+    }
+    const int j = (int)rint(m * 128.0);                             // nearest table point, 91 .. 181
+    const double mj = (double)j * (1.0 / 128.0);
+    const double *row = t.lg + 2 * (j - kLogTableLo);
+    const double r = (m - mj) * row[1];                             // |r| <= 1/181 (m - mj exact)
+    double p = GSSS_FMAK(r, -1.66666666666666666667e-01, 2.0e-01);  // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
+    p = GSSS_FMAK(p, r, -0.25);
+    p = GSSS_FMAK(p, r, 3.33333333333333333333e-01);
+    p = GSSS_FMAK(p, r, -0.5);
+    const double l1p = fma(r * r, p, r);
+    const double dk = (double)(e - 32);
+    return fma(dk, 6.93147180369123816490e-01, fma(dk, 1.90821492927058770002e-10, row[0] + l1p));
+}
+
 }  // namespace fm
 }  // namespace gsss

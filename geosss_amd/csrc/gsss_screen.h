@@ -313,7 +313,7 @@ __host__ __device__ constexpr bool screen_parks()
 template <int D, class TP, bool REPLAY>
 __host__ __device__ constexpr size_t screen_lds_doubles()
 {
-    return TP::lds_doubles() + (screen_parks<D, TP>() ? (size_t)(REPLAY ? ScreenChain<D, TP>::kWords
+    return TP::lds_doubles() + kTabLds + (screen_parks<D, TP>() ? (size_t)(REPLAY ? ScreenChain<D, TP>::kWords
                                                                         : ScreenChain<D, TP>::kWordsNoReplay) * kBlock
                                                       : 0);
 }
@@ -336,7 +336,8 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
-    unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles()) + threadIdx.x;
+    const fm::Tables tab = stage_tables(lds + TP::lds_doubles());
+    unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles() + kTabLds) + threadIdx.x;
     __syncthreads();
 
     const int32_t n = (int32_t)a.n_chains;
@@ -356,7 +357,8 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
 
     auto chain_id = [&]() { return slot ? id1 : id0; };
     auto philox = [&]() {
-        PhiloxDraws<V> dr;
+        PhiloxDraws<V, true> dr;
+        dr.tab = tab;
         dr.init(a, chain_id(), D);
         dr.begin_step(a.step_offset + (uint64_t)cur.steps_done);
         return dr;
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
             u_thr = replay_take();
             u_th0 = shrink ? replay_take() : 0.0;
         } else {
-            const PhiloxDraws<V> dr = philox();
+            const PhiloxDraws<V, true> dr = philox();
             dr.normals(cur.u, 0);
             dr.block(0u, u_thr, u_th0);
         }
@@ -498,7 +500,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
     auto finalise = [&]() {
         const double theta = cur.aux;
         double sn, cs;
-        fm::sincos_small(theta, sn, cs);
+        fm::sincos_tab(theta, tab, sn, cs);
         bool accepted = true;
         if (cur.status == kFinalDecide) {  // rare: the double-precision test itself (mcmc.py:389, 397)
             Coef cf;

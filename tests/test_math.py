@@ -97,3 +97,29 @@ def test_log(lib):
     y = np.empty_like(e)
     lib.t_log(_p(e), C.c_long(len(e)), _p(y))
     assert y[0] == -np.inf and np.isnan(y[1]) and np.isnan(y[2])
+
+
+def test_table_driven_functions(lib):
+    """The table-driven sincos / log of the throughput kernels (64 circle points, 129 log points, short polynomials):
+    as accurate as the polynomial versions."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-2 * np.pi, 2 * np.pi, 400000), np.linspace(-8, 8, 100001),
+                        np.array([0.0, np.pi / 64, -np.pi / 64, np.pi / 2, np.pi, 2 * np.pi, -2 * np.pi, 1e-300, 1e-9])])
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib.t_sincos_tab(_p(x), C.c_long(len(x)), _p(s), _p(c))
+    xl = x.astype(np.longdouble)
+    assert np.max(np.abs(s - np.sin(xl).astype(np.float64))) < 3.4e-16
+    assert np.max(np.abs(c - np.cos(xl).astype(np.float64))) < 3.4e-16
+    w = np.concatenate([rng.integers(0, 2**32, 400000, dtype=np.uint64), np.array([0, 1, 2**25 - 1, 2**25, 2**26, 2**31, 2**32 - 1])]).astype(np.uint32)
+    s, c = np.empty(len(w)), np.empty(len(w))
+    lib.t_sincos_word_tab(_p(w), C.c_long(len(w)), _p(s), _p(c))
+    a = 2 * np.longdouble("3.14159265358979323846264338327950288") * (w.astype(np.longdouble) / np.longdouble(2.0**32))
+    assert np.max(np.abs(s - np.sin(a).astype(np.float64))) < 3.4e-16
+    assert np.max(np.abs(c - np.cos(a).astype(np.float64))) < 3.4e-16
+    assert s[-7] == 0.0 and c[-7] == 1.0                                                    # w = 0
+    y = np.empty(len(w))
+    lib.t_log_word_tab(_p(w), C.c_long(len(w)), _p(y))
+    want = np.log((w.astype(np.longdouble) + 1) / np.longdouble(2.0**32)).astype(np.float64)
+    nz = want != 0
+    assert np.max(np.abs(y[nz] - want[nz]) / np.abs(want[nz])) < 1e-15
+    assert y[-1] == 0.0                                                                     # w = 2^32 - 1 -> log 1
