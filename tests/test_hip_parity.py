@@ -304,7 +304,7 @@ def test_readme_call_from_seed(gs):
     pdf = product_target(t)
     type(pdf).log_prob.reset_counters()
     s = gs.ShrinkageSphericalSliceSampler(pdf, np.array([-0.86, 0.19, -0.47]), 3521, rng="numpy")
-    assert s.mode == "fast"                      # one wavefront per chain, 16 speculative tries per step
+    assert s.mode == "fast"                      # one wavefront per chain, 8 speculative tries per step
     out = s.sample(1000, 100)
     assert out.shape == (1000, 3)
     assert np.max(np.abs(out - z["samples"])) < TOL
@@ -660,3 +660,38 @@ def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
     assert torch.equal(out[True][2], out[False][2])
     assert torch.equal(out[True][0], out[False][0])
     assert int(out[True][1].sum().item()) > 4 * n_chains * n_steps * (0.9 if sampler == "shrink" else 1.0)
+
+
+def test_auto_mode_warns_when_it_falls_back_to_the_exact_kernels(gs):
+    import warnings
+    from geosss_amd import mcmc
+    mcmc._warned_shapes.clear()
+    big = gs.Bingham(np.diag(np.arange(200.0)))
+    with pytest.warns(RuntimeWarning, match="no fast-mode kernel"):
+        s = gs.ShrinkageSphericalSliceSampler(big, np.eye(200)[0], 1)
+    assert s.mode == "exact"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # once per shape
+        gs.ShrinkageSphericalSliceSampler(big, np.eye(200)[0], 2)
+        z = golden("traj_vmfmix_readme.npz")
+        assert gs.ShrinkageSphericalSliceSampler(product_target(z), z["x0"], 1).mode == "fast"   # and never for a built shape
+
+
+@pytest.mark.parametrize("mode,placement", [("exact", "packed"), ("fast", "packed"), ("fast", "spread")])
+def test_replay_stream_too_short_is_flagged(gs, mode, placement):
+    """A replay stream that runs out sets GSSS_CHAIN_REPLAY_EXHAUSTED on that chain (and only there); the wrapper raises."""
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    n = 50
+    need = int(z["step_draw_offset"][n])
+    full = np.stack([z["draws"][:need], z["draws"][:need]])
+    short = full.copy()
+    short[1, need - 3:] = 0.5                                # same length on the device; chain 1 gets a truncated stride below
+    s = gs.ShrinkageSphericalSliceSampler(pdf, np.stack([z["x0"], z["x0"]]), 1, mode=mode, placement=placement)
+    s.advance(n, replay=full)
+    assert np.all(s.errors == 0) and np.max(np.abs(s.state - z["states"][n])) < TOL
+    t = gs.ShrinkageSphericalSliceSampler(pdf, z["x0"], 1, mode=mode, placement=placement)
+    t.advance(n, replay=z["draws"][None, : need - 3])
+    assert t.errors[0] & 4
+    with pytest.raises(gs._lib.GsssError):
+        t._check_errors()
