@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
     constexpr int kScr = kSpecPrefetched + 4 + NV;
     double *scr = sg + 4 * (size_t)nseg + (size_t)kScr * (threadIdx.x / 64);
     double *xch = scr + kSpecPrefetched + 4;
+    const fm::Tables tab = stage_tables(sg + 4 * (size_t)nseg + (size_t)kScr * (kBlock / 64));
     __syncthreads();
 
     const int lane = threadIdx.x % 64;
@@ -244,8 +245,8 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
             }
             {   // normals 4 lane .. 4 lane + 3 (block 1 + lane), zeros past d
                 double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-                box_muller32(w[0], w[1], z0, z1);
-                box_muller32(w[2], w[3], z2, z3);
+                box_muller32(w[0], w[1], tab, z0, z1);
+                box_muller32(w[2], w[3], tab, z2, z3);
                 const int c0 = 4 * lane;
                 u[0] = (lane < nq && c0 < d) ? z0 : 0.0;
                 u[1] = (lane < nq && c0 + 1 < d) ? z1 : 0.0;
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
                 }
             }
             double sn, cs;
-            fm::sincos_small(my_theta, sn, cs);
+            fm::sincos_tab(my_theta, tab, sn, cs);
             const double my_lvl = level_row(cs, sn);
             const bool ok = row < valid && t_base + row < a.max_tries && my_lvl > thr;  // mcmc.py:397
             const unsigned long long mask = __ballot(ok);
@@ -418,7 +419,7 @@ int do_curve64(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream
         set_error("in fast mode the numpy stream is served for lane-per-chain shapes only; use GSSS_MODE_EXACT");
         return GSSS_E_UNSUPPORTED;
     }
-    const size_t lds = ((size_t)tb.k * 256 + 4 * (size_t)(tb.k - 1) + (size_t)(kSpecPrefetched + 4 + NV) * (kBlock / 64)) *
+    const size_t lds = ((size_t)tb.k * 256 + 4 * (size_t)(tb.k - 1) + (size_t)(kSpecPrefetched + 4 + NV) * (kBlock / 64) + kTabLds) *
                        sizeof(double);
     auto kern = replay ? curve64_kernel<NV, true> : curve64_kernel<NV, false>;
     if (lds > 48 * 1024) {
