@@ -6,16 +6,17 @@ Drop-in for the slice-sampler path of microscopic-image-analysis/geosss:
     pdf = gs.MixtureModel([gs.VonMisesFisher(80.0 * mu) for mu in mus])
     samples = gs.ShrinkageSphericalSliceSampler(pdf, init_state, seed).sample(n_samples, burnin)
 """
-from . import _lib, diagnostics, sphere
+from . import _lib, diagnostics, registration, sphere
 from .diagnostics import IAT, acf, acf_fft, distance, n_eff
 from .distributions import (Bingham, BinghamFisher, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
                             brownian_curve, random_bingham)
 from .mcmc import (MetropolisHastings, RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, SphericalHMC,
                    determine_burnin)
+from .registration import CoherentPointDrift, GaussianMixtureModel, PointCloud, RotationProjection
 from .sphere import sample_sphere, sample_sphere_device
 from .utils import SamplerLauncher, count_calls, counter
 
 __all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
            "MetropolisHastings", "SphericalHMC", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
-           "sphere", "diagnostics", "IAT", "acf", "acf_fft", "distance", "n_eff"]
+           "sphere", "diagnostics", "registration", "CoherentPointDrift", "GaussianMixtureModel", "PointCloud", "RotationProjection", "IAT", "acf", "acf_fft", "distance", "n_eff"]

@@ -6,12 +6,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSSS_HIP_LIB") or os.path.join(_HERE, "libgsss_hip.so")  # env: side-by-side A/B builds
 
-VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
+VMF_MIXTURE, BINGHAM, CURVE_VMF, CPD = 1, 2, 3, 4
 SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
 MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GsssError(RuntimeError):
@@ -21,7 +21,10 @@ class GsssError(RuntimeError):
 class TargetDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("k", C.c_int32), ("reserved", C.c_int32),
                 ("mu", C.c_void_p), ("logc", C.c_void_p), ("A", C.c_void_p), ("knots", C.c_void_p),
-                ("kappa", C.c_double)]
+                ("kappa", C.c_double),
+                ("source", C.c_void_p), ("source_w", C.c_void_p), ("target", C.c_void_p), ("target_w", C.c_void_p),
+                ("n_target", C.c_int32), ("target_dim", C.c_int32), ("k_nn", C.c_int32), ("outlier", C.c_int32),
+                ("sigma", C.c_double), ("beta", C.c_double), ("omega", C.c_double), ("log_volume", C.c_double)]
 
 
 class RunArgs(C.Structure):

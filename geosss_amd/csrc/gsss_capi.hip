@@ -237,6 +237,12 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
 
 }  // namespace gsss
 
+namespace gsss {
+int launch_cpd_run(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
+int launch_cpd_rwmh(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st);
+int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st);
+}  // namespace gsss
+
 static int fast_dispatch(const gsss::TargetBlock &tb, const gsss::RunBlock &rb, bool replay, gsss::FastProbe *probe,
                          hipStream_t st)
 {
@@ -259,6 +265,7 @@ struct gsss_target {
     TargetBlock tb;
     double *blob_dev;
     size_t blob_doubles;
+    int cpd_variant;  // GSSS_CPD: which registration kernel (neighbour-list size, uniform source weights)
 };
 
 extern "C" {
@@ -293,6 +300,7 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     std::vector<double> blob;
     bool bingham_diagonal = false;
     double scale = 0.0;
+    int cpd_variant = 0;
     switch (desc->kind) {
     case GSSS_VMF_MIXTURE:
         if (k < 1 || !desc->mu || !desc->logc) {
@@ -349,6 +357,41 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
         }
         break;
     }
+    case GSSS_CPD: {
+        const int ns = k, nt = desc->n_target, dt = desc->target_dim, kn = desc->k_nn;
+        if (d != 4 || ns < 1 || ns > 65535 || nt < 1 || nt > 4000 || (dt != 2 && dt != 3) || kn < 1 || kn > 24 || kn > ns ||
+            !desc->source || !desc->source_w || !desc->target || !desc->target_w || !(desc->sigma > 0.0)) {
+            set_error("registration target needs d = 4, 1 <= k_nn <= min(24, source points), target_dim 2 or 3, sigma > 0, "
+                      "<= 65535 source and <= 4000 target points, and all four arrays");
+            return GSSS_E_INVALID;
+        }
+        if ((size_t)(4 * ns + 4 * nt + 8) * sizeof(double) > 150 * 1024) {
+            set_error("registration target: the point clouds do not fit the LDS");
+            return GSSS_E_UNSUPPORTED;
+        }
+        const double s2 = desc->sigma * desc->sigma;
+        // registration.py:215-219 (CoherentPointDrift) / :110-111 (GaussianMixtureModel)
+        const double log_const = (desc->outlier ? std::log(1.0 - desc->omega) : 0.0) - 0.5 * dt * std::log(2.0 * 3.141592653589793 * s2);
+        blob.assign(desc->source, desc->source + (size_t)3 * ns);
+        bool uniform = true;
+        for (int i = 0; i < ns; ++i) {
+            blob.push_back(std::log(desc->source_w[i]) + log_const);
+            uniform = uniform && desc->source_w[i] == desc->source_w[0];
+        }
+        for (int l = 0; l < nt; ++l)
+            for (int j = 0; j < 3; ++j) blob.push_back(j < dt ? desc->target[(size_t)l * dt + j] : 0.0);
+        blob.insert(blob.end(), desc->target_w, desc->target_w + nt);
+        blob.push_back(std::log(desc->omega + 1e-308) - desc->log_volume);  // registration.py:236
+        blob.push_back(0.5 / s2);
+        blob.push_back(desc->beta);
+        blob.push_back(desc->outlier ? 1.0 : 0.0);
+        blob.push_back((double)dt);
+        blob.push_back((double)kn);
+        blob.push_back(0.0);
+        blob.push_back(0.0);
+        cpd_variant = (kn <= 8 ? 0 : 2) + (uniform ? 0 : 1);
+        break;
+    }
     default:
         set_error("unknown target kind %d", desc->kind);
         return GSSS_E_INVALID;
@@ -379,6 +422,8 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     t->tb.kind = desc->kind;
     t->tb.d = d;
     t->tb.k = desc->kind == GSSS_BINGHAM ? (bingham_diagonal ? 1 : 0) : k;  // Bingham: k flags a diagonal A
+    if (desc->kind == GSSS_CPD) t->tb.k = k | (desc->n_target << 16);       // registration: both cloud sizes
+    t->cpd_variant = cpd_variant;
     t->tb.dpad = 0;
     t->tb.kappa = desc->kappa;
     t->tb.scale = scale;
@@ -413,6 +458,7 @@ int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *o
     case GSSS_VMF_MIXTURE: return launch_logprob<VmfMixture>(vec, t->tb, x_dev, n, out_dev, st);
     case GSSS_BINGHAM: return launch_logprob<Bingham>(vec, t->tb, x_dev, n, out_dev, st);
     case GSSS_CURVE_VMF: return launch_logprob<CurveVmf>(vec, t->tb, x_dev, n, out_dev, st);
+    case GSSS_CPD: return launch_cpd_logprob(t->cpd_variant, t->tb, x_dev, n, out_dev, st);
     }
     set_error("corrupt target");
     return GSSS_E_INVALID;
@@ -550,6 +596,13 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         mb.momenta = a->sampler == GSSS_HMC ? a->momenta_dev : nullptr;
         mb.adapt_steps = a->adapt_steps;
         mb.n_leapfrog = a->n_leapfrog;
+        if (t->tb.kind == GSSS_CPD) {
+            if (a->sampler == GSSS_HMC) {
+                set_error("spherical HMC needs the target's gradient: Registration.gradient is not built (use GSSS_RWMH or the slice samplers)");
+                return GSSS_E_UNSUPPORTED;
+            }
+            return launch_cpd_rwmh(t->cpd_variant, draws, t->tb, rb, mb, st);
+        }
         switch (t->tb.kind) {
         case GSSS_VMF_MIXTURE: return launch_mh<VmfMixture>(vec, draws, a->sampler, t->tb, rb, mb, st);
         case GSSS_BINGHAM: return launch_mh<Bingham>(vec, draws, a->sampler, t->tb, rb, mb, st);
@@ -557,6 +610,13 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         }
         set_error("corrupt target");
         return GSSS_E_INVALID;
+    }
+    if (t->tb.kind == GSSS_CPD) {
+        if (a->stats_dev) {
+            set_error("running statistics are not built for registration targets");
+            return GSSS_E_UNSUPPORTED;
+        }
+        return launch_cpd_run(t->cpd_variant, draws, t->tb, rb, st);
     }
     switch (t->tb.kind) {
     case GSSS_VMF_MIXTURE: return launch_run<VmfMixture>(vec, draws, t->tb, rb, st);

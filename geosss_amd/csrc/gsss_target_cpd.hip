@@ -1,0 +1,178 @@
+// Registration targets of geosss/registration.py on the device: CoherentPointDrift (:186-293) and
+// GaussianMixtureModel (:62-118) scored on a unit quaternion q (d = 4), one lane per chain:
+//
+//   log_prob(q) = beta * sum_l w_l * logsumexp( { log w_i - |y_l - T_q(x_i)|^2 / (2 sigma^2) + const : i in kNN(l) } [+ outlier] )
+//
+// R(q) = Rotation.from_quat(q).as_matrix() (pointcloud.py:101-115: scalar last, q normalised); T_q(x) = R x for a
+// PointCloud source (3-D target) or the first two rows of R x for a RotationProjection source (2-D target),
+// pointcloud.py:252-264, 280-293.  The reference builds a KD tree of the transformed source per evaluation and asks for
+// the k nearest; here every lane scans all source points (LDS broadcast reads) and keeps the KMAX smallest squared
+// distances in a register-resident sorted list (min / max insertion network) -- the same k nearest, no tree.
+// With a 3-D target the target point is rotated into the source frame instead (|y - R x| = |R^T y - x|): 6 flops a pair.
+#include "gsss_launch.h"
+#include "gsss_mh.h"
+
+namespace gsss {
+
+// tb.k packs the sizes: low 16 bits = source points, high bits = target points (both <= 65535)
+__host__ __device__ inline int cpd_ns(int k) { return k & 0xFFFF; }
+__host__ __device__ inline int cpd_nt(int k) { return (k >> 16) & 0xFFFF; }
+constexpr int kCpdConsts = 8;
+
+template <class V, int KMAX, bool UNIFORM_W>
+struct CpdTargetT {
+    static_assert(V::L == 1 && V::N == 4, "one lane per chain, quaternion state");
+    const double *src;  // LDS [ns][3]
+    const double *lw;   // LDS [ns]: log w_i + log_constant
+    const double *tgt;  // LDS [nt][3] (third component 0 for a 2-D target)
+    const double *tw;   // LDS [nt]
+    int ns, nt, dt, kn;
+    bool outlier;
+    double log_out, half_inv_s2, beta;
+
+    __host__ __device__ static size_t lds_doubles(int k, int /*d*/)
+    {
+        return 4 * (size_t)cpd_ns(k) + 4 * (size_t)cpd_nt(k) + kCpdConsts;
+    }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        ns = cpd_ns(tb.k);
+        nt = cpd_nt(tb.k);
+        const int total = 4 * ns + 4 * nt + kCpdConsts;
+        for (int i = threadIdx.x; i < total; i += kBlock) lds[i] = tb.blob[i];
+        src = lds;
+        lw = lds + 3 * ns;
+        tgt = lw + ns;
+        tw = tgt + 3 * nt;
+        const double *c = tb.blob + 4 * ns + 4 * nt;  // consts straight from global memory (uniform)
+        log_out = c[0];
+        half_inv_s2 = c[1];
+        beta = c[2];
+        outlier = c[3] != 0.0;
+        dt = (int)c[4];
+        kn = (int)c[5];
+    }
+    // (d^2 [, lw]) into the sorted list: the list keeps its KMAX smallest keys
+    __device__ __forceinline__ void insert(double (&key)[KMAX], double (&val)[KMAX], double k, double v) const
+    {
+#pragma unroll
+        for (int a = 0; a < KMAX; ++a) {
+            if constexpr (UNIFORM_W) {
+                const double lo = fmin(key[a], k);
+                k = fmax(key[a], k);
+                key[a] = lo;
+            } else {
+                const bool sw = k < key[a];
+                const double ko = sw ? key[a] : k, vo = sw ? val[a] : v;
+                key[a] = sw ? k : key[a];
+                val[a] = sw ? v : val[a];
+                k = ko;
+                v = vo;
+            }
+        }
+    }
+    __device__ double logp(const double (&q)[4], int /*g*/, double * /*scratch*/) const
+    {
+        const double nq = sqrt(fma(q[0], q[0], fma(q[1], q[1], fma(q[2], q[2], q[3] * q[3]))));
+        const double x = q[0] / nq, y = q[1] / nq, z = q[2] / nq, w = q[3] / nq;
+        const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+        const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+        const double r00 = x2 - y2 - z2 + w2, r01 = 2.0 * (xy - zw), r02 = 2.0 * (xz + yw);
+        const double r10 = 2.0 * (xy + zw), r11 = -x2 + y2 - z2 + w2, r12 = 2.0 * (yz - xw);
+        const double r20 = 2.0 * (xz - yw), r21 = 2.0 * (yz + xw), r22 = -x2 - y2 + z2 + w2;
+        const double lw0 = lw[0];
+        double total = 0.0;
+        for (int l = 0; l < nt; ++l) {
+            const double t0 = tgt[3 * l], t1 = tgt[3 * l + 1], t2 = tgt[3 * l + 2];
+            double key[KMAX], val[KMAX];
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) {
+                key[a] = INFINITY;
+                val[a] = -INFINITY;
+            }
+            if (dt == 3) {
+                // the target point in the source frame: R^T y
+                const double u0 = fma(r00, t0, fma(r10, t1, r20 * t2)), u1 = fma(r01, t0, fma(r11, t1, r21 * t2));
+                const double u2 = fma(r02, t0, fma(r12, t1, r22 * t2));
+                for (int i = 0; i < ns; ++i) {
+                    const double d0 = u0 - src[3 * i], d1 = u1 - src[3 * i + 1], d2 = u2 - src[3 * i + 2];
+                    insert(key, val, fma(d0, d0, fma(d1, d1, d2 * d2)), UNIFORM_W ? 0.0 : lw[i]);
+                }
+            } else {
+                for (int i = 0; i < ns; ++i) {
+                    const double s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
+                    const double d0 = t0 - fma(r00, s0, fma(r01, s1, r02 * s2)), d1 = t1 - fma(r10, s0, fma(r11, s1, r12 * s2));
+                    insert(key, val, fma(d0, d0, d1 * d1), UNIFORM_W ? 0.0 : lw[i]);
+                }
+            }
+            // logsumexp over the kn nearest (and the outlier column), registration.py:232-245
+            double amax = outlier ? log_out : -INFINITY;
+            double term[KMAX];
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) {
+                term[a] = a < kn ? fma(-half_inv_s2, key[a], UNIFORM_W ? lw0 : val[a]) : -INFINITY;
+                amax = fmax(amax, term[a]);
+            }
+            double sum = outlier ? fm::exp_fast(log_out - amax) : 0.0;
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a)
+                if (a < kn) sum += fm::exp_fast(term[a] - amax);
+            total = fma(tw[l], amax + fm::log_fast(sum), total);
+        }
+        return beta * total;
+    }
+    // (Registration.gradient is not built: HMC on a registration target is refused by gsss_run)
+    __device__ void grad(const double (&)[4], int, double *, double (&out)[4]) const { out[0] = out[1] = out[2] = out[3] = 0.0; }
+    static constexpr int kScratchPerChain = 0;
+};
+
+template <class V> using Cpd8U = CpdTargetT<V, 8, true>;
+template <class V> using Cpd8W = CpdTargetT<V, 8, false>;
+template <class V> using Cpd24U = CpdTargetT<V, 24, true>;
+template <class V> using Cpd24W = CpdTargetT<V, 24, false>;
+
+template <template <class> class TT>
+static int cpd_run(int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
+{
+    if (draws == kDrawsReplay) return do_run<VL4, TT, ReplayDraws>(tb, rb, st);
+    if (draws == kDrawsNumpy) return do_run<VL4, TT, NumpyDraws>(tb, rb, st);
+    return do_run<VL4, TT, PhiloxDraws>(tb, rb, st);
+}
+template <template <class> class TT>
+static int cpd_rwmh(int draws, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
+{
+    if (draws == kDrawsReplay) return do_mh<VL4, TT, ReplayDraws, GSSS_RWMH>(tb, rb, mb, st);
+    if (draws == kDrawsNumpy) return do_mh<VL4, TT, NumpyDraws, GSSS_RWMH>(tb, rb, mb, st);
+    return do_mh<VL4, TT, PhiloxDraws, GSSS_RWMH>(tb, rb, mb, st);
+}
+
+// variant: 0 = 8 neighbours / uniform weights, 1 = 8 / weighted, 2 = 24 / uniform, 3 = 24 / weighted
+int launch_cpd_run(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
+{
+    switch (variant) {
+    case 0: return cpd_run<Cpd8U>(draws, tb, rb, st);
+    case 1: return cpd_run<Cpd8W>(draws, tb, rb, st);
+    case 2: return cpd_run<Cpd24U>(draws, tb, rb, st);
+    default: return cpd_run<Cpd24W>(draws, tb, rb, st);
+    }
+}
+int launch_cpd_rwmh(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
+{
+    switch (variant) {
+    case 0: return cpd_rwmh<Cpd8U>(draws, tb, rb, mb, st);
+    case 1: return cpd_rwmh<Cpd8W>(draws, tb, rb, mb, st);
+    case 2: return cpd_rwmh<Cpd24U>(draws, tb, rb, mb, st);
+    default: return cpd_rwmh<Cpd24W>(draws, tb, rb, mb, st);
+    }
+}
+int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st)
+{
+    switch (variant) {
+    case 0: return do_logprob<VL4, Cpd8U>(tb, x, n, out, st);
+    case 1: return do_logprob<VL4, Cpd8W>(tb, x, n, out, st);
+    case 2: return do_logprob<VL4, Cpd24U>(tb, x, n, out, st);
+    default: return do_logprob<VL4, Cpd24W>(tb, x, n, out, st);
+    }
+}
+
+}  // namespace gsss

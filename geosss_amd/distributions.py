@@ -66,14 +66,16 @@ def log_bessel_i0(kappa):
 class _DeviceTarget:
     """Owns one gsss_target handle (device parameter block)."""
 
-    def __init__(self, desc_arrays, kind, d, k, kappa, device):
+    def __init__(self, desc_arrays, kind, d, k, kappa, device, extra=None):
         _lib.require_device()
         self.lib = _lib.load()
         self.device = device
-        self._keep = desc_arrays  # keep the host arrays alive during create
+        self._keep = (desc_arrays, extra)  # keep the host arrays alive during create
         desc = _lib.TargetDesc(kind, d, k, 0,
                                *[a.ctypes.data_as(C.c_void_p) if a is not None else None for a in desc_arrays],
                                float(kappa))
+        for name, value in (extra or {}).items():  # registration targets: the further fields of gsss_target_desc
+            setattr(desc, name, value.ctypes.data_as(C.c_void_p) if isinstance(value, np.ndarray) else value)
         h = C.c_void_p()
         _lib.check(self.lib.gsss_target_create(C.byref(desc), device, C.byref(h)))
         self.handle = h
@@ -96,14 +98,18 @@ class Distribution:
 
     def _device_target(self, device=None):
         dev = _device_index(device)
-        kind, d, k, kappa, arrays = self._pack()
+        packed = self._pack()
+        kind, d, k, kappa, arrays = packed[:5]
+        extra = packed[5] if len(packed) > 5 else None
         # the parameter attributes are public and mutable, as in the reference: key the device copy on
         # their current bytes so that an edited target is re-uploaded instead of silently reused
         key = (kind, d, k, kappa) + tuple(a.tobytes() if a is not None else None for a in arrays)
+        if extra:
+            key += tuple(v.tobytes() if isinstance(v, np.ndarray) else v for v in extra.values())
         cache = self.__dict__.setdefault("_targets", {})
         hit = cache.get(dev)
         if hit is None or hit[0] != key:
-            cache[dev] = (key, _DeviceTarget(arrays, kind, d, k, kappa, dev))
+            cache[dev] = (key, _DeviceTarget(arrays, kind, d, k, kappa, dev, extra))
         return cache[dev][1]
 
     def _invalidate(self):

@@ -79,7 +79,7 @@ _warned_shapes = set()
 def _warn_exact_fallback(distribution):
     """mode='auto' landed on the generic (exact) kernels: say so once per target shape."""
     key = (type(distribution).__name__, distribution.d)
-    if key in _warned_shapes:
+    if key in _warned_shapes or hasattr(distribution, "source"):  # (registration targets have no restricted form)
         return
     _warned_shapes.add(key)
     warnings.warn(f"geosss_amd: no fast-mode kernel covers this {key[0]} target (d={key[1]}); mode='auto' uses the "

@@ -1,0 +1,142 @@
+"""Rigid registration targets on unit quaternions, API-compatible with geosss/registration.py and the parts of
+geosss/pointcloud.py they need:
+
+    PointCloud(positions, weights=None)                         pointcloud.py:206-270
+    RotationProjection(positions, weights=None)                 pointcloud.py:273-293   (3-D source, 2-D target)
+    GaussianMixtureModel(target, source, sigma, k, beta=1)      registration.py:62-118
+    CoherentPointDrift(target, source, sigma, k, beta=1, omega=0)   registration.py:186-293
+    quat2matrix, matrix2quat                                    pointcloud.py:101-132
+
+`log_prob(rotation)` takes a unit quaternion (x, y, z, w) -- the state of the samplers, S^3 -- or rows of them, or a 3x3
+rotation matrix as the reference does, and is evaluated on the GPU (one lane per quaternion; a brute-force scan of the
+source cloud with a register-resident list of the k nearest replaces the reference's per-evaluation KD tree).  The slice
+samplers and MetropolisHastings run on these targets (exact mode); `gradient` (needed by SphericalHMC only) is not built.
+Translations are not part of the sampled state (the reference's samplers never pass one either).
+"""
+import numpy as np
+
+from . import _lib
+from .distributions import Distribution, _as_f64, counted
+
+__all__ = ["PointCloud", "RotationProjection", "GaussianMixtureModel", "CoherentPointDrift", "quat2matrix", "matrix2quat"]
+
+
+def quat2matrix(q):
+    """Rotation.from_quat(q).as_matrix() (pointcloud.py:101-115): scalar last, the quaternion is normalised."""
+    q = np.asarray(q, dtype=np.float64)
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([[x * x - y * y - z * z + w * w, 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), -x * x + y * y - z * z + w * w, 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), -x * x - y * y + z * z + w * w]])
+
+
+def matrix2quat(R):
+    """Rotation.from_matrix(R).as_quat() (pointcloud.py:118-132), scalar last."""
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_matrix(np.asarray(R, dtype=np.float64)).as_quat()
+
+
+class PointCloud:
+    """Weighted point cloud in 2-D or 3-D (pointcloud.py:206-270)."""
+
+    def __init__(self, positions, weights=None):
+        if np.ndim(positions) != 2:
+            raise ValueError("Expected rank-2 array")
+        if np.shape(positions)[1] not in (2, 3):
+            raise ValueError("Expected 2d or 3d point cloud")
+        self.positions = np.array(positions, dtype=np.float64)
+        self.weights = np.ones(len(self.positions)) if weights is None else np.array(weights, dtype=np.float64)
+
+    @property
+    def dim(self):
+        return self.positions.shape[1]
+
+    @property
+    def size(self):
+        return self.positions.shape[0]
+
+    @property
+    def center_of_mass(self):
+        return self.weights @ self.positions / self.weights.sum()
+
+    def transform_positions(self, rotation, translation=None):
+        rotation = quat2matrix(rotation) if np.shape(rotation)[-1] == 4 else np.asarray(rotation, dtype=np.float64)
+        if translation is None:
+            translation = np.zeros(len(rotation))
+        return self.positions.dot(rotation.T) + translation
+
+    def transform(self, rotation, translation=None):
+        self.positions = self.transform_positions(rotation, translation)
+
+
+class RotationProjection(PointCloud):
+    """Rotation of a 3-D cloud followed by the parallel projection onto the xy plane (pointcloud.py:273-293)."""
+
+    def transform_positions(self, rotation, translation=None):
+        rotation = quat2matrix(rotation) if np.shape(rotation)[-1] == 4 else np.asarray(rotation, dtype=np.float64)
+        if translation is None:
+            translation = np.zeros(self.dim - 1)
+        return self.positions @ rotation[:-1].T + translation
+
+
+class GaussianMixtureModel(Distribution):
+    """Gaussian mixture score of a rigid pose over the k nearest transformed source points of every target point
+    (registration.py:62-118)."""
+
+    _outlier = False
+
+    def __init__(self, target, source, sigma=1.0, k=20, *, beta=1.0):
+        self.target, self.source = target, source
+        self.sigma, self.k, self.beta = float(sigma), int(k), float(beta)
+        self.omega = 0.0
+
+    @property
+    def d(self):
+        return 4
+
+    def _pack(self):
+        src, tgt = self.source, self.target
+        if src.dim != 3:
+            raise ValueError("the source cloud must be 3-D")
+        want = 2 if isinstance(src, RotationProjection) else 3
+        if tgt.dim != want:
+            raise ValueError(f"a {type(src).__name__} source needs a {want}-D target")
+        log_volume = float(np.sum(np.log(np.ptp(tgt.positions, 0)))) if self._outlier else 0.0   # registration.py:207-213
+        extra = dict(source=_as_f64(src.positions), source_w=_as_f64(src.weights), target=_as_f64(tgt.positions),
+                     target_w=_as_f64(tgt.weights), n_target=tgt.size, target_dim=tgt.dim, k_nn=self.k,
+                     outlier=int(self._outlier), sigma=self.sigma, beta=self.beta, omega=self.omega, log_volume=log_volume)
+        return _lib.CPD, 4, src.size, 0.0, (None, None, None, None), extra
+
+    @staticmethod
+    def _as_quaternions(rotation):
+        r = np.asarray(rotation, dtype=np.float64) if not hasattr(rotation, "is_cuda") else rotation
+        if not hasattr(r, "is_cuda") and r.shape == (3, 3):
+            return matrix2quat(r)
+        return r
+
+    @counted
+    def log_prob(self, rotation, translation=None):
+        """beta * score of the pose (registration.py:47-53); `rotation`: quaternion (4,), rows (n, 4) or a 3x3 matrix."""
+        if translation is not None and np.any(np.asarray(translation) != 0):
+            raise NotImplementedError("translations are not part of the sampled state")
+        return self._log_prob_device(self._as_quaternions(rotation))
+
+    def gradient(self, rotation, translation=None):
+        raise NotImplementedError("Registration.gradient (registration.py:55-60) is not built: use the slice samplers or RWMH")
+
+
+class CoherentPointDrift(GaussianMixtureModel):
+    """GaussianMixtureModel plus a uniform outlier component of weight omega over the target's bounding box
+    (registration.py:186-250)."""
+
+    _outlier = True
+
+    def __init__(self, target, source, sigma=1.0, k=20, *, beta=1.0, omega=0.0):
+        super().__init__(target, source, sigma, k, beta=beta)
+        self.omega = float(omega)
+
+    @counted
+    def log_prob(self, rotation, translation=None):
+        if translation is not None and np.any(np.asarray(translation) != 0):
+            raise NotImplementedError("translations are not part of the sampled state")
+        return self._log_prob_device(self._as_quaternions(rotation))

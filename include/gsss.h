@@ -32,12 +32,13 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 5
+#define GSSS_ABI_VERSION 6
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
 #define GSSS_BINGHAM 2     /* Bingham                         :36-103            */
 #define GSSS_CURVE_VMF 3   /* CurvedVonMisesFisher+SlerpCurve :261-278, spherical_curve.py:10-32,74-102 */
+#define GSSS_CPD 4         /* registration.py: CoherentPointDrift :186-293 / GaussianMixtureModel :62-118 on unit quaternions (d = 4) */
 
 /* samplers (geosss/mcmc.py) */
 #define GSSS_SHRINK 0 /* ShrinkageSphericalSliceSampler.__next__  :382-401 */
@@ -77,6 +78,7 @@ typedef struct gsss_target gsss_target; /* opaque; owns a small device parameter
  *   BINGHAM:     A[d][d] symmetric (distributions.py:67-70); if mu is non-NULL it is the vector b[d] of a
  *       BinghamFisher target, log_prob = x^T A x + x.b (distributions.py:106-114).
  *   CURVE_VMF:   knots[k][d] unit vectors, kappa (distributions.py:263-265).
+ *   CPD:         see the fields below; GSSS_MODE_EXACT, lane-per-chain kernels; samplers GSSS_SHRINK / GSSS_REJECT / GSSS_RWMH.
  */
 typedef struct gsss_target_desc {
     int32_t kind;
@@ -88,6 +90,22 @@ typedef struct gsss_target_desc {
     const double *A;
     const double *knots;
     double kappa;
+    /* GSSS_CPD: rigid registration of a 3-D source cloud onto a 3-D target (PointCloud source, pointcloud.py:206-270) or onto a
+     * 2-D target after projection (RotationProjection source, :273-293).  The state is a unit quaternion (x, y, z, w), d = 4;
+     * log_prob(q) = beta * sum_l w_l logsumexp_{i in kNN(l)} [ log w_i - |y_l - R(q) x_i|^2 / (2 sigma^2) + const ] with the
+     * outlier term of CoherentPointDrift when `outlier` (registration.py:47-53, 103-118, 215-250).  k = number of source points. */
+    const double *source;   /* [k][3] */
+    const double *source_w; /* [k] */
+    const double *target;   /* [n_target][target_dim] */
+    const double *target_w; /* [n_target] */
+    int32_t n_target;
+    int32_t target_dim;     /* 3 or 2 */
+    int32_t k_nn;           /* neighbours per target point, <= 24 and <= k */
+    int32_t outlier;        /* 1: CoherentPointDrift, 0: GaussianMixtureModel */
+    double sigma;
+    double beta;
+    double omega;
+    double log_volume;      /* sum_j log(ptp(target[:, j]))  (registration.py:207-213) */
 } gsss_target_desc;
 
 /*

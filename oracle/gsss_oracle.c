@@ -22,6 +22,7 @@
  *   gor_step (shrink)           geosss/mcmc.py:382-401
  *   gor_step (reject)           geosss/mcmc.py:357-374
  *   gor_run                     geosss/mcmc.py:55-77 (the sampling loop, many chains)
+ *   gor_logprob (CPD / GMM)     geosss/registration.py:47-53, 103-118, 215-250; pointcloud.py:101-115, 252-264, 280-293
  *   gor_gradient                geosss/distributions.py:88-89, 159-160, 223-227, 277-278
  *   gor_mh_run (RWMH)           geosss/mcmc.py:138-167 with AdaptiveStepsize :80-115
  *   gor_mh_run (spherical HMC)  geosss/mcmc.py:236-318
@@ -56,6 +57,7 @@
 #define GOR_VMF_MIXTURE 1
 #define GOR_BINGHAM 2
 #define GOR_CURVE_VMF 3
+#define GOR_CPD 4 /* registration.py: CoherentPointDrift / GaussianMixtureModel on unit quaternions (d = 4) */
 
 #define GOR_SHRINK 0
 #define GOR_REJECT 1
@@ -75,6 +77,15 @@ typedef struct {
     const double *b;       /* [d] or NULL: BinghamFisher linear term (distributions.py:106-114) */
     const double *knots;   /* [k][d]  SlerpCurve knots (spherical_curve.py:37,79) */
     double kappa;          /* curve concentration (distributions.py:265) */
+    /* GOR_CPD (registration.py:65-293): k = number of source points */
+    const double *src;     /* [k][3]  source.positions (pointcloud.py:213-231) */
+    const double *src_w;   /* [k]     source.weights */
+    const double *tgt;     /* [n_target][target_dim] target.positions */
+    const double *tgt_w;   /* [n_target] target.weights */
+    int32_t n_target, target_dim; /* 3: PointCloud source (3D-3D); 2: RotationProjection source (3D-2D, pointcloud.py:273-293) */
+    int32_t k_nn;          /* neighbours per target point (registration.py:103) */
+    int32_t outlier;       /* 1: CoherentPointDrift (outlier column, :186-293); 0: GaussianMixtureModel (:62-118) */
+    double sigma, beta, omega, log_volume; /* log_volume = sum(log(ptp(target.positions, 0))) (registration.py:207-213) */
 } gor_target;
 
 /* ------------------------------------------------------------------ sphere.py */
@@ -195,6 +206,64 @@ double gor_logprob(const gor_target *t, const double *x)
         }
         if (t->b) s += gor_dot(x, t->b, d); /* distributions.py:113-114 */
         return s;
+    }
+    if (t->kind == GOR_CPD) {
+        /* Registration.log_prob (registration.py:47-53): R = quat2matrix(q) = Rotation.from_quat(q).as_matrix()
+         * (pointcloud.py:101-115; scipy normalises the quaternion, scalar last), then beta * _log_prob_R(R) */
+        double nq = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+        double qx = x[0] / nq, qy = x[1] / nq, qz = x[2] / nq, qw = x[3] / nq;
+        double x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, w2 = qw * qw;
+        double xy = qx * qy, zw = qz * qw, xz = qx * qz, yw = qy * qw, yz = qy * qz, xw = qx * qw;
+        double R[3][3] = {{x2 - y2 - z2 + w2, 2 * (xy - zw), 2 * (xz + yw)},
+                          {2 * (xy + zw), -x2 + y2 - z2 + w2, 2 * (yz - xw)},
+                          {2 * (xz - yw), 2 * (yz + xw), -x2 - y2 + z2 + w2}};
+        int ns = t->k, dt = t->target_dim, kn = t->k_nn;
+        /* transform_positions: positions @ R.T (3D, pointcloud.py:252-264) or positions @ R[:-1].T (projection, :280-293) */
+        double *p = (double *)malloc(sizeof(double) * (size_t)ns * 3);
+        for (int i = 0; i < ns; ++i)
+            for (int j = 0; j < dt; ++j)
+                p[3 * i + j] = R[j][0] * t->src[3 * i] + R[j][1] * t->src[3 * i + 1] + R[j][2] * t->src[3 * i + 2];
+        double *d2 = (double *)malloc(sizeof(double) * (size_t)ns);
+        int *idx = (int *)malloc(sizeof(int) * (size_t)ns);
+        double *terms = (double *)malloc(sizeof(double) * (size_t)(kn + 1));
+        double s2 = t->sigma * t->sigma;
+        /* registration.py:215-219 (CPD) / :110-111 (GMM) */
+        double log_const = t->outlier ? log(1.0 - t->omega) - 0.5 * dt * log(2.0 * 3.141592653589793 * s2)
+                                      : -(0.5 * dt * log(2.0 * 3.141592653589793 * s2));
+        double log_out = log(t->omega + 1e-308) - t->log_volume; /* registration.py:236 */
+        double total = 0.0;
+        for (int l = 0; l < t->n_target; ++l) {
+            for (int i = 0; i < ns; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < dt; ++j) {
+                    double df = t->tgt[(size_t)l * dt + j] - p[3 * i + j];
+                    acc += df * df;
+                }
+                d2[i] = acc;
+                idx[i] = i;
+            }
+            /* KDTree(trans_src).query(target, k): the k nearest, ascending (registration.py:95-101) */
+            for (int a = 0; a < kn; ++a) {
+                int best = a;
+                for (int i = a + 1; i < ns; ++i)
+                    if (d2[idx[i]] < d2[idx[best]]) best = i;
+                int tmp = idx[a];
+                idx[a] = idx[best];
+                idx[best] = tmp;
+            }
+            for (int a = 0; a < kn; ++a) {
+                double dist = sqrt(d2[idx[a]]); /* the tree returns distances; the score squares them again */
+                terms[a] = log(t->src_w[idx[a]]) + (-0.5 * dist * dist / s2) + log_const;
+            }
+            int nt = kn;
+            if (t->outlier) terms[nt++] = log_out;
+            total += gor_logsumexp(terms, nt) * t->tgt_w[l]; /* registration.py:118, 250 */
+        }
+        free(p);
+        free(d2);
+        free(idx);
+        free(terms);
+        return t->beta * total;
     }
     if (t->kind == GOR_CURVE_VMF) {
         /* distributions.py:272-275 */

@@ -13,7 +13,7 @@ from scipy.special import i0, ive
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "libgsss_oracle.so")
 
-VMF_MIXTURE, BINGHAM, CURVE_VMF = 1, 2, 3
+VMF_MIXTURE, BINGHAM, CURVE_VMF, CPD = 1, 2, 3, 4
 SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
 ERR_MAX_TRIES, ERR_NONFINITE, ERR_REPLAY_EXHAUSTED = 1, 2, 4
 
@@ -28,7 +28,10 @@ def build(force=False):
 class _Target(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("k", C.c_int32),
                 ("mu", C.c_void_p), ("lognorm", C.c_void_p), ("logw", C.c_void_p),
-                ("A", C.c_void_p), ("b", C.c_void_p), ("knots", C.c_void_p), ("kappa", C.c_double)]
+                ("A", C.c_void_p), ("b", C.c_void_p), ("knots", C.c_void_p), ("kappa", C.c_double),
+                ("src", C.c_void_p), ("src_w", C.c_void_p), ("tgt", C.c_void_p), ("tgt_w", C.c_void_p),
+                ("n_target", C.c_int32), ("target_dim", C.c_int32), ("k_nn", C.c_int32), ("outlier", C.c_int32),
+                ("sigma", C.c_double), ("beta", C.c_double), ("omega", C.c_double), ("log_volume", C.c_double)]
 
 
 _lib = None
@@ -95,8 +98,24 @@ class Target:
         return cls(CURVE_VMF, knots.shape[1], knots.shape[0], knots=knots, kappa=kappa)
 
     @classmethod
+    def cpd(cls, source, source_w, target, target_w, sigma, k_nn, beta=1.0, omega=0.0, outlier=True):
+        """CoherentPointDrift / GaussianMixtureModel of geosss/registration.py on unit quaternions."""
+        source, target = _f64(source), _f64(target)
+        t = cls(CPD, 4, len(source))
+        t.src, t.src_w, t.tgt, t.tgt_w = source, _f64(source_w), target, _f64(target_w)
+        log_volume = float(np.sum(np.log(np.ptp(target, 0))))                   # registration.py:207-213
+        t.c = _Target(CPD, 4, len(source), None, None, None, None, None, None, 0.0, _p(t.src), _p(t.src_w), _p(t.tgt),
+                      _p(t.tgt_w), len(target), target.shape[1], int(k_nn), int(bool(outlier)), float(sigma), float(beta),
+                      float(omega), log_volume)
+        return t
+
+    @classmethod
     def from_fixture(cls, z, prefix="target_"):
         kind = str(z[prefix + "kind"])
+        if kind == "cpd":
+            return cls.cpd(z[prefix + "source"], z[prefix + "source_w"], z[prefix + "target"], z[prefix + "target_w"],
+                           float(z[prefix + "sigma"]), int(z[prefix + "k_nn"]), float(z[prefix + "beta"]),
+                           float(z[prefix + "omega"]), bool(z[prefix + "outlier"]))
         if kind == "vmf_mixture":
             return cls.vmf_mixture(z[prefix + "mu"], z[prefix + "weights"])
         if kind == "bingham":

@@ -145,6 +145,12 @@ def record_trajectory(cls, pdf, x0, seed, n_steps):
 
 def target_params(pdf):
     """Flatten a reference pdf into the plain arrays our C-ABI takes."""
+    from geosss.registration import CoherentPointDrift, GaussianMixtureModel
+    if isinstance(pdf, GaussianMixtureModel):  # registration.py:62-293 (CoherentPointDrift is a subclass)
+        return dict(kind="cpd", source=np.array(pdf.source.positions, dtype=float), source_w=np.array(pdf.source.weights, dtype=float),
+                    target=np.array(pdf.target.positions, dtype=float), target_w=np.array(pdf.target.weights, dtype=float),
+                    sigma=np.float64(pdf.sigma), k_nn=np.int64(pdf.k), beta=np.float64(pdf.beta),
+                    omega=np.float64(getattr(pdf, "omega", 0.0)), outlier=np.bool_(isinstance(pdf, CoherentPointDrift)))
     if isinstance(pdf, gs.MixtureModel):
         mu = np.array([p.mu for p in pdf.pdfs])
         return dict(kind="vmf_mixture", mu=mu, weights=np.array(pdf.weights))
@@ -443,8 +449,48 @@ def make_mh():
             save(f"mh_{kind}_{name}.npz", x0=np.array(x0), grad_X=X, grad=grad, **flat_params(target_params(pdf)), **rec)
 
 
+def cpd_cases():
+    """Registration targets (geosss/registration.py) on unit quaternions: the protein example of
+    scripts/protein_reg3d3d.py:561-594 (data/protein_registration.npz: 214 + 214 points, sigma 1, k 20, omega 0.4), the
+    3D-2D toy of tests/test_cpd.py:79-107 with seeded noise, and a GaussianMixtureModel (no outlier term)."""
+    from geosss.pointcloud import PointCloud, RotationMatrix, RotationProjection
+    from geosss.registration import CoherentPointDrift, GaussianMixtureModel
+    data = np.load(os.path.join(REF, "data", "protein_registration.npz"))
+    n = len(data["source"])
+    prot_t, prot_s = PointCloud(data["target"]), PointCloud(data["source"], np.full(n, 1 / n))
+    out = {"cpd_protein": CoherentPointDrift(prot_t, prot_s, sigma=float(data["sigma"]), k=20, omega=float(data["prob_outlier"]))}
+    out["gmm_protein_k10"] = GaussianMixtureModel(prot_t, prot_s, sigma=2.0, k=10, beta=0.5)
+    rng = np.random.default_rng(5)
+    cube = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
+    src = RotationProjection(cube)
+    R_true = RotationMatrix().rotation3d(euler_angles=np.array([0.2, 0.3, 0.1]))
+    tgt = src.transform_positions(R_true) + rng.normal(0, 0.05, (8, 2))
+    tgt = np.vstack([tgt, rng.uniform(-3, 3, (4, 2))])
+    out["cpd_cube_3d2d"] = CoherentPointDrift(PointCloud(tgt), src, sigma=0.5, k=8, omega=0.2)
+    return out
+
+
+def make_cpd():
+    rng = np.random.default_rng(99)
+    for name, pdf in cpd_cases().items():
+        Q = rsphere.radial_projection(rng.standard_normal((48, 4)))
+        Q[40:] *= rng.uniform(0.5, 1.5, size=(8, 1))                    # non-unit quaternions: quat2matrix normalises
+        logp = np.array([float(pdf.log_prob(q)) for q in Q])
+        x0 = rsphere.radial_projection(np.random.default_rng(7).standard_normal(4))
+        n = 40 if "protein" in name else 150
+        rec = record_trajectory(gs.ShrinkageSphericalSliceSampler, pdf, x0, 321, n)
+        print(f"{name}: {n} slice steps, rej/step={rec['n_reject'] / n:.2f}, min margin={rec['min_margin']:.2e}")
+        save(f"traj_{name}.npz", x0=x0, sampler=np.array("shrink"), kat_q=Q, kat_logp=logp,
+             **flat_params(target_params(pdf)), **rec)
+        mh = record_mh("rwmh", pdf, x0, 654, 80 if "protein" in name else 200, 30, 0.1)
+        print(f"rwmh_{name}: accept rate {mh['n_accept'] / len(mh['accept']):.2f}")
+        save(f"mh_rwmh_{name}.npz", x0=x0, grad_X=np.zeros((0, 4)), grad=np.zeros((0, 4)), **flat_params(target_params(pdf)), **mh)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh"]
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh", "cpd"]
+    if "cpd" in what:
+        make_cpd()
     if "mh" in what:
         make_mh()
     if "timing" in what:

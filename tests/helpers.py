@@ -16,6 +16,14 @@ def product_target(z, prefix="target_"):
         return gs.Bingham(z[prefix + "A"])
     if kind == "curve_vmf":
         return gs.CurvedVonMisesFisher(gs.SlerpCurve(z[prefix + "knots"]), float(z[prefix + "kappa"]))
+    if kind == "cpd":
+        tgt = gs.PointCloud(z[prefix + "target"], z[prefix + "target_w"])
+        cloud = gs.RotationProjection if z[prefix + "target"].shape[1] == 2 else gs.PointCloud
+        src = cloud(z[prefix + "source"], z[prefix + "source_w"])
+        if bool(z[prefix + "outlier"]):
+            return gs.CoherentPointDrift(tgt, src, float(z[prefix + "sigma"]), int(z[prefix + "k_nn"]),
+                                         beta=float(z[prefix + "beta"]), omega=float(z[prefix + "omega"]))
+        return gs.GaussianMixtureModel(tgt, src, float(z[prefix + "sigma"]), int(z[prefix + "k_nn"]), beta=float(z[prefix + "beta"]))
     raise ValueError(kind)
 
 
@@ -46,6 +54,8 @@ FAST_CURVE = {(d, 10) for d in (3, 6, 9, 10, 12, 15, 18, 21, 24)}  # (d, knots)
 
 def fast_supported(z, prefix="target_"):
     kind = str(z[prefix + "kind"])
+    if kind == "cpd":
+        return False
     if kind == "vmf_mixture":
         k, d = z[prefix + "mu"].shape
         return k <= 16 and d <= 256  # lane kernels d <= 10 (component buckets), cooperative fast kernels beyond

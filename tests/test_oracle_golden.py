@@ -174,3 +174,13 @@ def test_numpy_port_reproduces_reference_chain():
     out, rej = numpy_port.run_chain(numpy_port.VmfMixture(t["target_mu"], t["target_weights"]), t["x0"], 300, 3521)
     assert np.max(np.abs(out - t["states"][1:301])) < 1e-12
     assert rej == int((t["tries"][:300] - 1).sum())
+
+
+@pytest.mark.parametrize("name", ["traj_cpd_protein", "traj_gmm_protein_k10", "traj_cpd_cube_3d2d"])
+def test_registration_log_prob_kat(oracle, name):
+    """CoherentPointDrift / GaussianMixtureModel.log_prob (geosss/registration.py) at 48 quaternions, unit and not: the
+    oracle's brute-force k nearest neighbours against the reference's KDTree."""
+    z = golden(name + ".npz")
+    tgt = oracle.Target.from_fixture(z)
+    got = tgt.log_prob(z["kat_q"])
+    assert np.max(np.abs(got - z["kat_logp"]) / np.maximum(1.0, np.abs(z["kat_logp"]))) < TOL

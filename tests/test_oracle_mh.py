@@ -32,6 +32,8 @@ def _run(oracle, z, **kw):
 @pytest.mark.parametrize("name", CASES)
 def test_gradient_kat(oracle, name):
     z = golden(name + ".npz")
+    if len(z["grad_X"]) == 0:
+        pytest.skip("registration targets: log_prob only (RWMH); their gradient is not restated")
     tgt = oracle.Target.from_fixture(z)
     got = np.array([oracle.gradient(tgt, x) for x in z["grad_X"]])
     assert np.max(np.abs(got - z["grad"]) / np.maximum(1.0, np.abs(z["grad"]))) < 1e-12
