@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
 
 namespace gsss {
 int launch_cpd_run(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
-int launch_cpd_rwmh(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st);
+int launch_cpd_mh(int variant, int draws, int sampler, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st);
 int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st);
 }  // namespace gsss
 
@@ -596,13 +596,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         mb.momenta = a->sampler == GSSS_HMC ? a->momenta_dev : nullptr;
         mb.adapt_steps = a->adapt_steps;
         mb.n_leapfrog = a->n_leapfrog;
-        if (t->tb.kind == GSSS_CPD) {
-            if (a->sampler == GSSS_HMC) {
-                set_error("spherical HMC needs the target's gradient: Registration.gradient is not built (use GSSS_RWMH or the slice samplers)");
-                return GSSS_E_UNSUPPORTED;
-            }
-            return launch_cpd_rwmh(t->cpd_variant, draws, t->tb, rb, mb, st);
-        }
+        if (t->tb.kind == GSSS_CPD) return launch_cpd_mh(t->cpd_variant, draws, a->sampler, t->tb, rb, mb, st);
         switch (t->tb.kind) {
         case GSSS_VMF_MIXTURE: return launch_mh<VmfMixture>(vec, draws, a->sampler, t->tb, rb, mb, st);
         case GSSS_BINGHAM: return launch_mh<Bingham>(vec, draws, a->sampler, t->tb, rb, mb, st);

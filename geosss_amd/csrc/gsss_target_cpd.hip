@@ -121,8 +121,97 @@ struct CpdTargetT {
         }
         return beta * total;
     }
-    // (Registration.gradient is not built: HMC on a registration target is refused by gsss_run)
-    __device__ void grad(const double (&)[4], int, double *, double (&out)[4]) const { out[0] = out[1] = out[2] = out[3] = 0.0; }
+    // Registration.gradient (registration.py:55-60): J^T vec(beta * _grad_R), _grad_R of :120-160 / :252-293 (posterior
+    // weights gamma clipped to [e^-20, 1]) and the Jacobian d(M / r)/dq of pointcloud.py:135-204 (the two minus signs of the
+    // reference cancel).  Needs the neighbours' indices: a (distance, index) insertion network.
+    __device__ void grad(const double (&q)[4], int /*g*/, double * /*scratch*/, double (&out)[4]) const
+    {
+        const double nq = sqrt(fma(q[0], q[0], fma(q[1], q[1], fma(q[2], q[2], q[3] * q[3]))));
+        const double x = q[0] / nq, y = q[1] / nq, z = q[2] / nq, w = q[3] / nq;
+        const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+        const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+        const double r00 = x2 - y2 - z2 + w2, r01 = 2.0 * (xy - zw), r02 = 2.0 * (xz + yw);
+        const double r10 = 2.0 * (xy + zw), r11 = -x2 + y2 - z2 + w2, r12 = 2.0 * (yz - xw);
+        const double r20 = 2.0 * (xz - yw), r21 = 2.0 * (yz + xw), r22 = -x2 - y2 + z2 + w2;
+        double g00 = 0.0, g01 = 0.0, g02 = 0.0, g10 = 0.0, g11 = 0.0, g12 = 0.0, g20 = 0.0, g21 = 0.0, g22 = 0.0;
+        const double inv_s2 = 2.0 * half_inv_s2;
+        for (int l = 0; l < nt; ++l) {
+            const double t0 = tgt[3 * l], t1 = tgt[3 * l + 1], t2 = tgt[3 * l + 2];
+            double key[KMAX];
+            int idx[KMAX];
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) {
+                key[a] = INFINITY;
+                idx[a] = 0;
+            }
+            const double u0 = fma(r00, t0, fma(r10, t1, r20 * t2)), u1 = fma(r01, t0, fma(r11, t1, r21 * t2));
+            const double u2 = fma(r02, t0, fma(r12, t1, r22 * t2));
+            for (int i = 0; i < ns; ++i) {
+                const double s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
+                double k;
+                if (dt == 3) {
+                    const double d0 = u0 - s0, d1 = u1 - s1, d2 = u2 - s2;
+                    k = fma(d0, d0, fma(d1, d1, d2 * d2));
+                } else {
+                    const double d0 = t0 - fma(r00, s0, fma(r01, s1, r02 * s2)), d1 = t1 - fma(r10, s0, fma(r11, s1, r12 * s2));
+                    k = fma(d0, d0, d1 * d1);
+                }
+                int v = i;
+#pragma unroll
+                for (int a = 0; a < KMAX; ++a) {
+                    const bool sw = k < key[a];
+                    const double ko = sw ? key[a] : k;
+                    const int vo = sw ? idx[a] : v;
+                    key[a] = sw ? k : key[a];
+                    idx[a] = sw ? v : idx[a];
+                    k = ko;
+                    v = vo;
+                }
+            }
+            double amax = outlier ? log_out : -INFINITY;
+            double term[KMAX];
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) {
+                term[a] = a < kn ? fma(-half_inv_s2, key[a], lw[idx[a]]) : -INFINITY;
+                amax = fmax(amax, term[a]);
+            }
+            double sum = outlier ? fm::exp_fast(log_out - amax) : 0.0;
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a)
+                if (a < kn) sum += fm::exp_fast(term[a] - amax);
+            const double lse = amax + fm::log_fast(sum);
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) {
+                if (a < kn) {
+                    const double lg = fmin(fmax(term[a] - lse, -20.0), 0.0);
+                    const double coeff = tw[l] * fm::exp_fast(lg) * inv_s2;
+                    const double s0 = src[3 * idx[a]], s1 = src[3 * idx[a] + 1], s2 = src[3 * idx[a] + 2];
+                    const double d0 = t0 - fma(r00, s0, fma(r01, s1, r02 * s2)), d1 = t1 - fma(r10, s0, fma(r11, s1, r12 * s2));
+                    const double d2 = dt == 3 ? t2 - fma(r20, s0, fma(r21, s1, r22 * s2)) : 0.0;
+                    g00 = fma(coeff * d0, s0, g00); g01 = fma(coeff * d0, s1, g01); g02 = fma(coeff * d0, s2, g02);
+                    g10 = fma(coeff * d1, s0, g10); g11 = fma(coeff * d1, s1, g11); g12 = fma(coeff * d1, s2, g12);
+                    g20 = fma(coeff * d2, s0, g20); g21 = fma(coeff * d2, s1, g21); g22 = fma(coeff * d2, s2, g22);
+                }
+            }
+        }
+        // dR/dq_c = dM/dq_c / r - 2 q_c M / r^2 with the quaternion as given (r = |q|^2 + 1e-300)
+        const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+        const double r = qw * qw + qx * qx + qy * qy + qz * qz + 1e-300;
+        const double m00 = qw * qw + qx * qx - qy * qy - qz * qz, m01 = 2.0 * (qx * qy - qw * qz), m02 = 2.0 * (qw * qy + qx * qz);
+        const double m10 = 2.0 * (qw * qz + qx * qy), m11 = qw * qw - qx * qx + qy * qy - qz * qz, m12 = 2.0 * (qy * qz - qw * qx);
+        const double m20 = 2.0 * (qx * qz - qw * qy), m21 = 2.0 * (qw * qx + qy * qz), m22 = qw * qw - qx * qx - qy * qy + qz * qz;
+        const double mg = m00 * g00 + m01 * g01 + m02 * g02 + m10 * g10 + m11 * g11 + m12 * g12 + m20 * g20 + m21 * g21 + m22 * g22;
+        // sum_ji dM_ji/dq_c g_ji for c = x, y, z, w
+        const double dx = 2.0 * (qx * g00 + qy * g01 + qz * g02 + qy * g10 - qx * g11 - qw * g12 + qz * g20 + qw * g21 - qx * g22);
+        const double dy = 2.0 * (-qy * g00 + qx * g01 + qw * g02 + qx * g10 + qy * g11 + qz * g12 - qw * g20 + qz * g21 - qy * g22);
+        const double dz = 2.0 * (-qz * g00 - qw * g01 + qx * g02 + qw * g10 - qz * g11 + qy * g12 + qx * g20 + qy * g21 + qz * g22);
+        const double dw = 2.0 * (qw * g00 - qz * g01 + qy * g02 + qz * g10 + qw * g11 - qx * g12 - qy * g20 + qx * g21 + qw * g22);
+        const double f = 2.0 * mg / (r * r);
+        out[0] = beta * (dx / r - qx * f);
+        out[1] = beta * (dy / r - qy * f);
+        out[2] = beta * (dz / r - qz * f);
+        out[3] = beta * (dw / r - qw * f);
+    }
     static constexpr int kScratchPerChain = 0;
 };
 
@@ -139,11 +228,9 @@ static int cpd_run(int draws, const TargetBlock &tb, const RunBlock &rb, hipStre
     return do_run<VL4, TT, PhiloxDraws>(tb, rb, st);
 }
 template <template <class> class TT>
-static int cpd_rwmh(int draws, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
+static int cpd_rwmh(int draws, int sampler, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
 {
-    if (draws == kDrawsReplay) return do_mh<VL4, TT, ReplayDraws, GSSS_RWMH>(tb, rb, mb, st);
-    if (draws == kDrawsNumpy) return do_mh<VL4, TT, NumpyDraws, GSSS_RWMH>(tb, rb, mb, st);
-    return do_mh<VL4, TT, PhiloxDraws, GSSS_RWMH>(tb, rb, mb, st);
+    return mh_dispatch<VL4, TT>(draws, sampler, tb, rb, mb, st);
 }
 
 // variant: 0 = 8 neighbours / uniform weights, 1 = 8 / weighted, 2 = 24 / uniform, 3 = 24 / weighted
@@ -156,13 +243,13 @@ int launch_cpd_run(int variant, int draws, const TargetBlock &tb, const RunBlock
     default: return cpd_run<Cpd24W>(draws, tb, rb, st);
     }
 }
-int launch_cpd_rwmh(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
+int launch_cpd_mh(int variant, int draws, int sampler, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
 {
     switch (variant) {
-    case 0: return cpd_rwmh<Cpd8U>(draws, tb, rb, mb, st);
-    case 1: return cpd_rwmh<Cpd8W>(draws, tb, rb, mb, st);
-    case 2: return cpd_rwmh<Cpd24U>(draws, tb, rb, mb, st);
-    default: return cpd_rwmh<Cpd24W>(draws, tb, rb, mb, st);
+    case 0: return cpd_rwmh<Cpd8U>(draws, sampler, tb, rb, mb, st);
+    case 1: return cpd_rwmh<Cpd8W>(draws, sampler, tb, rb, mb, st);
+    case 2: return cpd_rwmh<Cpd24U>(draws, sampler, tb, rb, mb, st);
+    default: return cpd_rwmh<Cpd24W>(draws, sampler, tb, rb, mb, st);
     }
 }
 int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st)

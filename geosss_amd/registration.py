@@ -10,7 +10,8 @@ geosss/pointcloud.py they need:
 `log_prob(rotation)` takes a unit quaternion (x, y, z, w) -- the state of the samplers, S^3 -- or rows of them, or a 3x3
 rotation matrix as the reference does, and is evaluated on the GPU (one lane per quaternion; a brute-force scan of the
 source cloud with a register-resident list of the k nearest replaces the reference's per-evaluation KD tree).  The slice
-samplers and MetropolisHastings run on these targets (exact mode); `gradient` (needed by SphericalHMC only) is not built.
+samplers, MetropolisHastings and SphericalHMC run on these targets (exact mode; `Registration.gradient` is evaluated
+inside the HMC kernel -- there is no host-callable gradient).
 Translations are not part of the sampled state (the reference's samplers never pass one either).
 """
 import numpy as np
@@ -122,7 +123,7 @@ class GaussianMixtureModel(Distribution):
         return self._log_prob_device(self._as_quaternions(rotation))
 
     def gradient(self, rotation, translation=None):
-        raise NotImplementedError("Registration.gradient (registration.py:55-60) is not built: use the slice samplers or RWMH")
+        raise NotImplementedError("Registration.gradient (registration.py:55-60) is evaluated inside the HMC kernel only")
 
 
 class CoherentPointDrift(GaussianMixtureModel):

@@ -182,6 +182,112 @@ double gor_logsumexp(const double *a, int n)
     return log1p(s / (double)m) + log((double)m) + amax;
 }
 
+/* ------------------------------------------------------------------ registration.py */
+
+/* R = Rotation.from_quat(q).as_matrix() (pointcloud.py:101-115): scalar last, q normalised */
+static void gor_quat2matrix(const double *x, double R[3][3])
+{
+    double nq = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    double qx = x[0] / nq, qy = x[1] / nq, qz = x[2] / nq, qw = x[3] / nq;
+    double x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, w2 = qw * qw;
+    double xy = qx * qy, zw = qz * qw, xz = qx * qz, yw = qy * qw, yz = qy * qz, xw = qx * qw;
+    double M[3][3] = {{x2 - y2 - z2 + w2, 2 * (xy - zw), 2 * (xz + yw)},
+                      {2 * (xy + zw), -x2 + y2 - z2 + w2, 2 * (yz - xw)},
+                      {2 * (xz - yw), 2 * (yz + xw), -x2 - y2 + z2 + w2}};
+    memcpy(R, M, sizeof(M));
+}
+
+/* Registration.log_prob (registration.py:47-53) of CoherentPointDrift (:215-250) / GaussianMixtureModel (:103-118) at the
+ * quaternion x; if grad_q != NULL also Registration.gradient (:55-60) = J^T vec(beta * _grad_R) with _grad_R of :120-160 /
+ * :252-293 and the Jacobian of pointcloud.py:135-204 */
+static double gor_cpd(const gor_target *t, const double *x, double *grad_q)
+{
+    double R[3][3];
+    gor_quat2matrix(x, R);
+    int ns = t->k, dt = t->target_dim, kn = t->k_nn;
+    /* transform_positions: positions @ R.T (3D, pointcloud.py:252-264) or positions @ R[:-1].T (projection, :280-293) */
+    double *p = (double *)calloc((size_t)ns * 3, sizeof(double));
+    for (int i = 0; i < ns; ++i)
+        for (int j = 0; j < dt; ++j)
+            p[3 * i + j] = R[j][0] * t->src[3 * i] + R[j][1] * t->src[3 * i + 1] + R[j][2] * t->src[3 * i + 2];
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)ns);
+    int *idx = (int *)malloc(sizeof(int) * (size_t)ns);
+    double *terms = (double *)malloc(sizeof(double) * (size_t)(kn + 1));
+    double s2 = t->sigma * t->sigma;
+    /* registration.py:215-219 (CPD) / :110-111 (GMM) */
+    double log_const = t->outlier ? log(1.0 - t->omega) - 0.5 * dt * log(2.0 * 3.141592653589793 * s2)
+                                  : -(0.5 * dt * log(2.0 * 3.141592653589793 * s2));
+    double log_out = log(t->omega + 1e-308) - t->log_volume; /* registration.py:236 */
+    double total = 0.0;
+    double gR[3][3] = {{0.0}};
+    for (int l = 0; l < t->n_target; ++l) {
+        for (int i = 0; i < ns; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < dt; ++j) {
+                double df = t->tgt[(size_t)l * dt + j] - p[3 * i + j];
+                acc += df * df;
+            }
+            d2[i] = acc;
+            idx[i] = i;
+        }
+        /* KDTree(trans_src).query(target, k): the k nearest, ascending (registration.py:95-101) */
+        for (int a = 0; a < kn; ++a) {
+            int best = a;
+            for (int i = a + 1; i < ns; ++i)
+                if (d2[idx[i]] < d2[idx[best]]) best = i;
+            int tmp = idx[a];
+            idx[a] = idx[best];
+            idx[best] = tmp;
+        }
+        for (int a = 0; a < kn; ++a) {
+            double dist = sqrt(d2[idx[a]]); /* the tree returns distances; the score squares them again */
+            terms[a] = log(t->src_w[idx[a]]) + (-0.5 * dist * dist / s2) + log_const;
+        }
+        int nt = kn;
+        if (t->outlier) terms[nt++] = log_out;
+        double lse = gor_logsumexp(terms, nt);
+        total += lse * t->tgt_w[l]; /* registration.py:118, 250 */
+        if (grad_q) {
+            for (int a = 0; a < kn; ++a) {
+                double lg = terms[a] - lse;             /* registration.py:137-139, 262-264: clip(log gamma, -20, 0) */
+                lg = lg < -20.0 ? -20.0 : (lg > 0.0 ? 0.0 : lg);
+                double coeff = t->tgt_w[l] * exp(lg) / s2;
+                for (int j = 0; j < 3; ++j) {            /* d_lk = y_l (padded) - x_k_trans (padded), :151-157 */
+                    double yl = j < dt ? t->tgt[(size_t)l * dt + j] : 0.0;
+                    double dj = yl - p[3 * idx[a] + j];
+                    for (int i = 0; i < 3; ++i) gR[j][i] += coeff * dj * t->src[3 * idx[a] + i]; /* einsum "lk,lkj,lki->ji" */
+                }
+            }
+        }
+    }
+    free(p);
+    free(d2);
+    free(idx);
+    free(terms);
+    if (grad_q) {
+        /* _grad_R returns -grad_R, jacobian_rotation_matrix returns -J: grad_q = beta * J^T vec(grad_R) with
+         * J = d (M / r) / dq, M the unnormalised rotation entries, r = |q|^2 + 1e-300 (pointcloud.py:135-204) */
+        double qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+        double r = qw * qw + qx * qx + qy * qy + qz * qz + 1e-300;
+        double M[3][3] = {{qw * qw + qx * qx - qy * qy - qz * qz, 2 * (qx * qy - qw * qz), 2 * (qw * qy + qx * qz)},
+                          {2 * (qw * qz + qx * qy), qw * qw - qx * qx + qy * qy - qz * qz, 2 * (qy * qz - qw * qx)},
+                          {2 * (qx * qz - qw * qy), 2 * (qw * qx + qy * qz), qw * qw - qx * qx - qy * qy + qz * qz}};
+        /* dM/dq_c, c = x, y, z, w */
+        double dM[4][3][3] = {
+            {{2 * qx, 2 * qy, 2 * qz}, {2 * qy, -2 * qx, -2 * qw}, {2 * qz, 2 * qw, -2 * qx}},
+            {{-2 * qy, 2 * qx, 2 * qw}, {2 * qx, 2 * qy, 2 * qz}, {-2 * qw, 2 * qz, -2 * qy}},
+            {{-2 * qz, -2 * qw, 2 * qx}, {2 * qw, -2 * qz, 2 * qy}, {2 * qx, 2 * qy, 2 * qz}},
+            {{2 * qw, -2 * qz, 2 * qy}, {2 * qz, 2 * qw, -2 * qx}, {-2 * qy, 2 * qx, 2 * qw}}};
+        for (int c = 0; c < 4; ++c) {
+            double acc = 0.0;
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i) acc += (dM[c][j][i] / r - 2.0 * x[c] * M[j][i] / (r * r)) * gR[j][i];
+            grad_q[c] = t->beta * acc;
+        }
+    }
+    return t->beta * total;
+}
+
 double gor_logprob(const gor_target *t, const double *x)
 {
     int d = t->d;
@@ -207,64 +313,7 @@ double gor_logprob(const gor_target *t, const double *x)
         if (t->b) s += gor_dot(x, t->b, d); /* distributions.py:113-114 */
         return s;
     }
-    if (t->kind == GOR_CPD) {
-        /* Registration.log_prob (registration.py:47-53): R = quat2matrix(q) = Rotation.from_quat(q).as_matrix()
-         * (pointcloud.py:101-115; scipy normalises the quaternion, scalar last), then beta * _log_prob_R(R) */
-        double nq = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-        double qx = x[0] / nq, qy = x[1] / nq, qz = x[2] / nq, qw = x[3] / nq;
-        double x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, w2 = qw * qw;
-        double xy = qx * qy, zw = qz * qw, xz = qx * qz, yw = qy * qw, yz = qy * qz, xw = qx * qw;
-        double R[3][3] = {{x2 - y2 - z2 + w2, 2 * (xy - zw), 2 * (xz + yw)},
-                          {2 * (xy + zw), -x2 + y2 - z2 + w2, 2 * (yz - xw)},
-                          {2 * (xz - yw), 2 * (yz + xw), -x2 - y2 + z2 + w2}};
-        int ns = t->k, dt = t->target_dim, kn = t->k_nn;
-        /* transform_positions: positions @ R.T (3D, pointcloud.py:252-264) or positions @ R[:-1].T (projection, :280-293) */
-        double *p = (double *)malloc(sizeof(double) * (size_t)ns * 3);
-        for (int i = 0; i < ns; ++i)
-            for (int j = 0; j < dt; ++j)
-                p[3 * i + j] = R[j][0] * t->src[3 * i] + R[j][1] * t->src[3 * i + 1] + R[j][2] * t->src[3 * i + 2];
-        double *d2 = (double *)malloc(sizeof(double) * (size_t)ns);
-        int *idx = (int *)malloc(sizeof(int) * (size_t)ns);
-        double *terms = (double *)malloc(sizeof(double) * (size_t)(kn + 1));
-        double s2 = t->sigma * t->sigma;
-        /* registration.py:215-219 (CPD) / :110-111 (GMM) */
-        double log_const = t->outlier ? log(1.0 - t->omega) - 0.5 * dt * log(2.0 * 3.141592653589793 * s2)
-                                      : -(0.5 * dt * log(2.0 * 3.141592653589793 * s2));
-        double log_out = log(t->omega + 1e-308) - t->log_volume; /* registration.py:236 */
-        double total = 0.0;
-        for (int l = 0; l < t->n_target; ++l) {
-            for (int i = 0; i < ns; ++i) {
-                double acc = 0.0;
-                for (int j = 0; j < dt; ++j) {
-                    double df = t->tgt[(size_t)l * dt + j] - p[3 * i + j];
-                    acc += df * df;
-                }
-                d2[i] = acc;
-                idx[i] = i;
-            }
-            /* KDTree(trans_src).query(target, k): the k nearest, ascending (registration.py:95-101) */
-            for (int a = 0; a < kn; ++a) {
-                int best = a;
-                for (int i = a + 1; i < ns; ++i)
-                    if (d2[idx[i]] < d2[idx[best]]) best = i;
-                int tmp = idx[a];
-                idx[a] = idx[best];
-                idx[best] = tmp;
-            }
-            for (int a = 0; a < kn; ++a) {
-                double dist = sqrt(d2[idx[a]]); /* the tree returns distances; the score squares them again */
-                terms[a] = log(t->src_w[idx[a]]) + (-0.5 * dist * dist / s2) + log_const;
-            }
-            int nt = kn;
-            if (t->outlier) terms[nt++] = log_out;
-            total += gor_logsumexp(terms, nt) * t->tgt_w[l]; /* registration.py:118, 250 */
-        }
-        free(p);
-        free(d2);
-        free(idx);
-        free(terms);
-        return t->beta * total;
-    }
+    if (t->kind == GOR_CPD) return gor_cpd(t, x, NULL);
     if (t->kind == GOR_CURVE_VMF) {
         /* distributions.py:272-275 */
         double *y = (double *)malloc(sizeof(double) * (size_t)d);
@@ -626,6 +675,8 @@ void gor_gradient(const gor_target *t, const double *x, double *g)
             g[i] = acc / den;
         }
         free(p);
+    } else if (t->kind == GOR_CPD) {
+        (void)gor_cpd(t, x, g);
     } else if (t->kind == GOR_BINGHAM) {
         for (int i = 0; i < d; ++i) g[i] = 2.0 * gor_dot(t->A + (size_t)i * d, x, d); /* distributions.py:88-89 : 2 * A @ x */
     } else {

@@ -482,9 +482,14 @@ def make_cpd():
         print(f"{name}: {n} slice steps, rej/step={rec['n_reject'] / n:.2f}, min margin={rec['min_margin']:.2e}")
         save(f"traj_{name}.npz", x0=x0, sampler=np.array("shrink"), kat_q=Q, kat_logp=logp,
              **flat_params(target_params(pdf)), **rec)
+        GX = rsphere.radial_projection(rng.standard_normal((24, 4)))
+        grad = np.array([pdf.gradient(q) for q in GX])                  # Registration.gradient, registration.py:55-60
         mh = record_mh("rwmh", pdf, x0, 654, 80 if "protein" in name else 200, 30, 0.1)
         print(f"rwmh_{name}: accept rate {mh['n_accept'] / len(mh['accept']):.2f}")
-        save(f"mh_rwmh_{name}.npz", x0=x0, grad_X=np.zeros((0, 4)), grad=np.zeros((0, 4)), **flat_params(target_params(pdf)), **mh)
+        save(f"mh_rwmh_{name}.npz", x0=x0, grad_X=GX, grad=grad, **flat_params(target_params(pdf)), **mh)
+        hm = record_mh("hmc", pdf, x0, 655, 30 if "protein" in name else 120, 10, 1e-3 if "protein" in name else 0.05)
+        print(f"hmc_{name}: accept rate {hm['n_accept'] / len(hm['accept']):.2f}, final stepsize {hm['stepsize_trace'][-1]:.2e}")
+        save(f"mh_hmc_{name}.npz", x0=x0, grad_X=GX, grad=grad, **flat_params(target_params(pdf)), **hm)
 
 
 if __name__ == "__main__":

@@ -63,11 +63,18 @@ def test_philox_stream_matches_oracle(gs, oracle, name, sampler):
     assert np.max(np.abs(s.state - want["state"])) < 1e-10
 
 
-def test_hmc_on_a_registration_target_is_refused(gs):
-    pdf = product_target(golden("traj_cpd_cube_3d2d.npz"))
-    h = gs.SphericalHMC(pdf, np.array([0.0, 0.0, 0.0, 1.0]), 1, stepsize=0.05)
-    with pytest.raises(ValueError, match="gradient"):
-        h.advance(2)
+def test_hmc_runs_on_a_registration_target(gs, oracle):
+    """SphericalHMC with Registration.gradient on the device: single transitions from 200 poses against the oracle (free
+    running chains part once rounding flips a nearest neighbour: tests/test_oracle_mh.py::horizon)."""
+    z = golden("traj_cpd_cube_3d2d.npz")
+    pdf, tgt = product_target(z), oracle.Target.from_fixture(z)
+    x0 = oracle.sample_sphere(2, 200, 4)
+    want = oracle.mh_run(tgt, x0, 1, sampler=oracle.HMC, stepsize=0.05, n_leapfrog=10, seed=8, n_threads=8)
+    h = gs.SphericalHMC(pdf, x0, 8, stepsize=0.05, n_steps=10)
+    h.advance(1)
+    assert np.array_equal(h.n_accept_per_chain, want["n_accept"])
+    assert np.max(np.abs(h.state[:, :4] - want["state"])) < 1e-10
+    assert np.max(np.abs(h.momenta - want["momenta"])) < 1e-9
 
 
 def test_registration_finds_the_pose(gs):
