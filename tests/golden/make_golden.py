@@ -487,7 +487,7 @@ def make_cpd():
         mh = record_mh("rwmh", pdf, x0, 654, 80 if "protein" in name else 200, 30, 0.1)
         print(f"rwmh_{name}: accept rate {mh['n_accept'] / len(mh['accept']):.2f}")
         save(f"mh_rwmh_{name}.npz", x0=x0, grad_X=GX, grad=grad, **flat_params(target_params(pdf)), **mh)
-        hm = record_mh("hmc", pdf, x0, 655, 30 if "protein" in name else 120, 10, 1e-3 if "protein" in name else 0.05)
+        hm = record_mh("hmc", pdf, x0, 655, 10 if "protein" in name else 120, 4 if "protein" in name else 10, 1e-3 if "protein" in name else 0.05)
         print(f"hmc_{name}: accept rate {hm['n_accept'] / len(hm['accept']):.2f}, final stepsize {hm['stepsize_trace'][-1]:.2e}")
         save(f"mh_hmc_{name}.npz", x0=x0, grad_X=GX, grad=grad, **flat_params(target_params(pdf)), **hm)
 
