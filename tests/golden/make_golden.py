@@ -300,7 +300,9 @@ def _stat_chain(args):
     rej_total = s.n_reject
     X = X[burn:]
     geo = np.arccos(np.clip(np.sum(X[1:] * X[:-1], axis=-1), -1, 1))
-    out = dict(mean=X.mean(0), second=(X[:, :, None] * X[:, None, :]).mean(0), rej_per_step=rej_total / (n_steps + burn - 1),
+    from geosss.utils import IAT
+    out = dict(iat=np.array([IAT(X[:, j]) for j in range(X.shape[1])]),  # per chain and coordinate, utils.py:119-131
+               mean=X.mean(0), second=(X[:, :, None] * X[:, None, :]).mean(0), rej_per_step=rej_total / (n_steps + burn - 1),
                geo_step=geo.mean(), logp_mean=np.mean(pdf.log_prob(X)) if name.startswith(("vmf", "bing")) else np.nan)
     if name.startswith("vmfmix"):
         modes = np.array([p.mu / np.linalg.norm(p.mu) for p in pdf.pdfs])

@@ -299,3 +299,22 @@ def test_published_mode_occupancy_is_a_typical_chain(gs):
     spread = occ.std(0)
     assert np.all(spread > 0.01)                                # chains do differ: the published scatter is expected
     assert np.max(np.abs(paper - 0.2) / spread) < 4.0, (paper, spread)
+
+
+@pytest.mark.parametrize("name,n_chains", [("vmfmix_readme", 512), ("bingham_d10_vmax30", 256)])
+def test_iat_z_test_against_reference_chains(gs, name, n_chains):
+    """Integrated autocorrelation time per coordinate with the reference's own estimator (utils.py:119-131) on chains of
+    the reference's length: the ensemble mean agrees with the mean over the 8 reference chains of stats_<name>.npz within
+    four standard errors (z-test; README target ~15 %, Bingham ~4 %)."""
+    z, st = golden(f"traj_{name}.npz"), golden(f"stats_{name}.npz")
+    pdf = product_target(z)
+    n_steps = int(st["n_steps"])
+    x0 = np.repeat(z["x0"][None], n_chains, axis=0)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77)
+    s.advance(n_steps // 10)                                             # the reference chains' burn-in
+    X = s.sample(n_steps, as_tensor=True)                                # (chains, draws, dims)
+    iat = gs.diagnostics.IAT(X.permute(0, 2, 1).contiguous()).cpu().numpy()   # (chains, dims)
+    ref_mean, ref_se = st["iat"].mean(0), st["iat"].std(0, ddof=1) / np.sqrt(len(st["iat"]))
+    se = np.sqrt(ref_se**2 + (iat.std(0, ddof=1) / np.sqrt(n_chains))**2)
+    zscore = (iat.mean(0) - ref_mean) / se
+    assert np.max(np.abs(zscore)) < 4.0, (zscore, iat.mean(0), ref_mean)
