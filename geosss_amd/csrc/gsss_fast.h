@@ -41,8 +41,9 @@ __device__ __forceinline__ double inv_norm(double s) { return s > 1e-200 ? rsqrt
 // ------------------------------------------------------------------------------------------
 // restricted targets (lane layout, D components in registers)
 //   make(cf, x, u, lvl, fresh)  coefficients of the circle through x along u; returns the level
-//                               of x (theta = 0).  `lvl` is the level the accepting try computed
-//                               for this very point: targets reuse it unless `fresh`.
+//                               of x (theta = 0), formed from x as the reference forms its threshold.
+//                               (`lvl`, `fresh`: the level carried over from the accepting try and the
+//                               first-step flag of round 1's carry scheme -- no target uses them any more.)
 //   level(cf, c, s)             level of y(theta); accept iff level > threshold
 //   kLinear                     level is a density (threshold = level(x) * U) rather than a
 //                               log-density (threshold = level(x) + log U)
@@ -110,7 +111,7 @@ struct FastVmf {
     // the accept test S > thr is decided by the bounds whenever thr is outside (lower, upper] -- the same
     // decision the full sum gives.  Otherwise (thr between the bounds: the other components matter, rare
     // for separated modes) the full double-precision sum is formed.  Returns a value that compares with
-    // `thr` exactly like the full sum; the level carried to the next step is recomputed in make().
+    // `thr` exactly like the full sum.
     static constexpr bool kScreened = KC >= 5;
     __device__ __forceinline__ double level_full(const double (&a)[KC]) const
     {

@@ -53,21 +53,19 @@ __device__ __forceinline__ float log2_32(double v)
 
 // ------------------------------------------------------------------------------------------
 // screening side of the restricted targets.  A target provides, next to gsss_fast.h's interface,
-//   Keep / kKeepWords      double-precision values that persist from step to step
-//   kCoef32Floats          size of the single-precision pack q[]
-//   coeffs(cf, x, u)       the double-precision coefficients again (bit-identical to make()'s)
-//   make32(cf, keep, thr, q)   single-precision pack + error margin for the step
-//   screen(q, c, s)        -1 reject / +1 accept (both certain) / 0 undecided
-//   level_exact(cf, keep, c, s)   the double-precision level fast_kernel compares with thr
-//   kCarry                 the accepted point's level is the next step's level of x
+//   kCoef32Floats              size of the single-precision pack q[]
+//   coeffs(cf, x, u)           the double-precision coefficients of the circle (bit-identical to make()'s)
+//   make32(cf, U, q)           single-precision pack and error margin for the step, from the coefficients and the
+//                              threshold uniform U; false if the level of x is not finite
+//   screen(q, c, s)            -1 reject / +1 accept (both certain) / 0 undecided
+//   threshold(cf, x, u, U)     the double-precision threshold exactly as fast_kernel forms it (undecided tries only)
+//   level_exact(cf, c, s)      the double-precision level fast_kernel compares with that threshold
 // ------------------------------------------------------------------------------------------
 template <int D, int KC>
 struct ScreenVmf : FastVmf<D, KC> {
     using Base = FastVmf<D, KC>;
     using Coef = typename Base::Coef;
-    static constexpr int kKeepWords = 0;
     static constexpr int kCoef32Floats = 3 * KC + 1;
-    static constexpr bool kCarry = false;  // the level of x is formed from x at set-up (make), as the reference does
 
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
@@ -143,8 +141,6 @@ struct ScreenVmf : FastVmf<D, KC> {
         for (int k = 0; k < KC; ++k) a[k] = fma(c, cf.ax[k], fma(s, cf.au[k], this->logc[k])) - cf.m;
         return this->level_full(a);
     }
-    __device__ __forceinline__ double keep_get(const Coef &) const { return 0.0; }
-    __device__ __forceinline__ void keep_set(Coef &, double) const {}
 };
 
 // Bingham / BinghamFisher: log-density q(theta) = c^2 qxx + c s qxu + s^2 quu + c bx + s bu (distributions.py:86, :113-114),
@@ -154,9 +150,7 @@ template <int D>
 struct ScreenBingham : FastBingham<D> {
     using Base = FastBingham<D>;
     using Coef = typename Base::Coef;
-    static constexpr int kKeepWords = 0;
     static constexpr int kCoef32Floats = 6;
-    static constexpr bool kCarry = false;
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
         (void)this->make(cf, x, u, 0.0, true);
@@ -197,9 +191,7 @@ template <int D, int NK>
 struct ScreenCurve : FastCurve<D, NK> {
     using Base = FastCurve<D, NK>;
     using Coef = typename Base::Coef;
-    static constexpr int kKeepWords = 0;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
-    static constexpr bool kCarry = false;
     const float4 *seg32;  // LDS [NK-1]: cos, sin, 1 / (sin + 1e-10) per segment in single precision (read as one broadcast b128)
     float inv_sin_min;
     __host__ __device__ static size_t lds_doubles() { return Base::lds_doubles() + 2 * (size_t)(NK - 1); }
@@ -297,11 +289,10 @@ struct ScreenChain {
     double lo, hi;
     double thr;   // the step's uniform U of the threshold (mcmc.py:389); the threshold itself is formed on demand
     double aux;   // kFinal*: theta of the stopped try
-    double keep;  // a target's persistent double, if it has one
     float q[kQ];
     uint32_t n_try;
     int32_t steps_done, row, t, status, err, cursor;
-    static constexpr int kWordsNoReplay = 2 * D + 4 + TP::kKeepWords + kQ / 2 + 2;
+    static constexpr int kWordsNoReplay = 2 * D + 4 + kQ / 2 + 2;
     static constexpr int kWords = kWordsNoReplay + 1;
 };
 
@@ -387,7 +378,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         for (int j = 0; j < D; ++j) cur.u[j] = 0.0;
 #pragma unroll
         for (int i = 0; i < Chain::kQ; ++i) cur.q[i] = 0.0f;
-        cur.lo = cur.hi = cur.thr = cur.aux = cur.keep = 0.0;
+        cur.lo = cur.hi = cur.thr = cur.aux = 0.0;
         cur.n_try = 0u;
         cur.steps_done = 0;
         cur.row = 0;
@@ -548,7 +539,6 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         word(cur.hi);
         word(cur.thr);
         word(cur.aux);
-        if (TP::kKeepWords) word(cur.keep);
 #pragma unroll
         for (int i = 0; i < Chain::kQ; i += 2) {
             lds_trade(cur.q[i], cur.q[i + 1], p);
@@ -603,7 +593,6 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         put(cur.hi);
         put(cur.thr);
         put(cur.aux);
-        if (TP::kKeepWords) put(cur.keep);
 #pragma unroll
         for (int i = 0; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
         put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
