@@ -1,0 +1,420 @@
+// gsss_curvespec.h -- curve-vMF targets at 9 <= d <= 256: L lanes per chain, L speculative tries per batch,
+// every try screened in single precision.
+//
+// The lane-per-chain kernels hold x, u and 2 NK coefficients of a chain in one lane: from d = 9 on that is more than
+// 256 vector registers (one wavefront per SIMD, and at the 10^5-chain ensembles of the reference's curve experiments not
+// even one wavefront for every SIMD).  The cooperative kernel of gsss_fast.h spreads a chain over 16 lanes but runs the
+// shrinkage loop one try after the other on nine of them.  Here a chain owns a GROUP of L = 4 (d <= 16) or 16 lanes:
+//
+//  1. The O(d) work of a step -- normals, projection, the dots with the knots, the state update -- is spread over the
+//     group (CoopVec<L, 4 Q>: lane g holds the component quads g, g + L, ...; all sums are DPP reductions, after which
+//     every lane of the group holds the same bits).
+//  2. The bracket sequence of a step does not depend on any log-density (mcmc.py:395, 400: while tries are rejected,
+//     theta_t and the shrunken bracket follow from the uniforms alone), so the group replays the recurrence for L tries,
+//     lane t evaluates try t -- the whole curve, all NK - 1 segments, in SINGLE precision on the hardware transcendentals
+//     with the rigorous margin of gsss_screen.h (Curve32) -- and a ballot picks the first try that is not certainly
+//     rejected.  Certainly accepted: the step ends there.  Undecided: that lane alone takes the double-precision decision
+//     (from the step's double-precision coefficients, parked in a few LDS words of the group), and the scan resumes.  The
+//     accepted try is the one the sequential loop stops at.  7.2 tries per step (kappa = 800) are 1.05 batches at L = 16.
+//  3. One or two Philox rounds per step: lane g draws the block of its normals; lanes without components draw block 0
+//     (threshold and theta_0 uniforms) and the blocks of the first tries; the uniforms travel through a few LDS words.
+//  4. a_i.x follows the recurrence a_i.x' = c a_i.x + s a_i.u between refreshes for L = 16 (as in coopfast_kernel);
+//     the L = 4 kernel forms it from x at every step, so its chains do not depend on how the steps are split over
+//     launches (bitwise, like the lane kernels it stands in for).
+//
+// Stream layout, arithmetic of the projection and of the restricted level: as in gsss_fast.h / gsss_spec64.h, so the
+// chains agree with the other fast kernels to rounding and with the oracle on the Philox stream in every integer output.
+// Semantics followed: geosss/mcmc.py:357-401, sphere.py:10-33, spherical_curve.py:10-32, 95-102, distributions.py:272-275.
+#pragma once
+#include "gsss_screen.h"
+
+namespace gsss {
+
+template <int L, int NK>
+__host__ __device__ constexpr int curvespec_scratch_doubles()
+{
+    return 2 + 4 * L + 2 * NK;  // U_threshold, U_theta0 | a ring of 4 L try uniforms | the step's double-precision coefficients
+}
+template <int L, int Q, int NK>
+__host__ __device__ constexpr size_t curvespec_lds_doubles()
+{
+    return (size_t)NK * (4 * Q * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
+           (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2;
+}
+
+template <int L, int Q, int NK, bool REPLAY>
+__global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(TargetBlock tb, RunBlock a)
+{
+    using V = CoopVec<L, 4 * Q>;
+    using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level
+    constexpr int DPAD = V::DPAD;
+    constexpr int N = V::N;
+    constexpr int kRing = 4 * L;
+    constexpr int kScratch = curvespec_scratch_doubles<L, NK>();
+    constexpr bool kRecur = L >= 16;  // a_i.x by recurrence between refreshes
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+
+    const int d = tb.d, k = tb.k;
+    // LDS: knots [NK][DPAD] | segments [NK-1][4] | the same in single precision | per group: scratch | tables
+    lds_fill(lds, k, DPAD, tb.blob, d);
+    for (int i = threadIdx.x + k * DPAD; i < NK * DPAD; i += kBlock) lds[i] = 0.0;
+    double *sg = lds + (size_t)NK * DPAD;
+    for (int i = threadIdx.x; i < NK - 1; i += kBlock) {  // blob: theta, cos, sin, sin + 1e-10
+        const bool real = i < k - 1;
+        sg[4 * i + 0] = real ? tb.blob[(size_t)k * d + 4 * i + 1] : 1.0;
+        sg[4 * i + 1] = real ? tb.blob[(size_t)k * d + 4 * i + 2] : 0.0;
+        sg[4 * i + 2] = real ? 1.0 / tb.blob[(size_t)k * d + 4 * i + 3] : 0.0;
+        sg[4 * i + 3] = 0.0;
+    }
+    __syncthreads();
+    Curve32<NK> c32;
+    c32.stage(reinterpret_cast<float4 *>(sg + 4 * (NK - 1)), sg, k - 1, tb.kappa);
+    double *scr = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (threadIdx.x / L);
+    double *ring = scr + 2;
+    double *coef = ring + kRing;  // [2 NK]: a_i.x | a_i.u of the step (for the double-precision decisions)
+    const fm::Tables tab = stage_tables(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L));
+    Scalar sc;
+    sc.knots = lds;
+    sc.seg = sg;
+    sc.kappa = tb.kappa;
+    sc.nseg = k - 1;
+    __syncthreads();
+
+    const int lane = threadIdx.x % 64;
+    const int g = lane % L;              // lane of the group
+    const int base = lane - g;           // first lane of the group in the wavefront
+    const int64_t n = a.n_chains;
+    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / L) + threadIdx.x / L;
+    const bool active = c_raw < n;
+    const int64_t c = active ? c_raw : n - 1;
+    const bool shrink = a.sampler == GSSS_SHRINK;
+    const int nq = (d + 3) >> 2;         // Philox blocks of the normals
+    const uint32_t try_base = 1u + (uint32_t)nq;
+    const int max_tries = a.max_tries;
+
+    double x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int cc = V::comp(g, i);
+        x[i] = (cc < d) ? a.state[(size_t)cc * n + c] : 0.0;
+    }
+
+    PhiloxDraws<V> dr;
+    dr.init(a, c, d);
+    const double *rp = REPLAY ? a.replay + (size_t)c * a.replay_stride : nullptr;
+    int64_t cursor = 0;
+    int err = 0;
+    double ax[NK];  // a_i . x (kRecur: carried from step to step)
+#pragma unroll
+    for (int r = 0; r < NK; ++r) ax[r] = 0.0;
+    int64_t n_try = 0;
+    int32_t steps_done = 0, until_keep = (int32_t)a.thin, row_out = 0;
+    bool alive = active && a.n_steps > 0;
+
+    auto wave_sync = [&]() {  // LDS words written by some lanes of the wavefront, read by others
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // one Philox round of "extra" blocks: extra index e = 0 is block 0, e >= 1 the tries' block e - 1
+    auto publish_extra = [&](int e, const uint32_t (&w)[4]) {
+        const double p0 = u53(w[0], w[1]), p1 = u53(w[2], w[3]);
+        if (e == 0) {
+            scr[0] = p0;
+            scr[1] = p1;
+        } else if (e > 0) {
+            const int t0 = 2 * (e - 1);
+            ring[t0 & (kRing - 1)] = p0;
+            ring[(t0 + 1) & (kRing - 1)] = p1;
+        }
+    };
+
+    for (int64_t s = 0; s < a.n_steps; ++s) {
+        if (!__any(alive)) break;
+        // The target's constants never change, so the compiler would hoist their LDS loads out of this loop and keep them
+        // in registers for the whole launch: the base is made opaque once per step.
+        const double *knots = lds;
+        asm volatile("" : "+s"(knots));
+        Scalar scl = sc;
+        scl.seg = knots + (size_t)NK * DPAD;
+        Curve32<NK> c32s = c32;
+        c32s.seg32 = reinterpret_cast<const float4 *>(knots + (size_t)NK * DPAD + 4 * (NK - 1));
+        // ---------------- draws of the step
+        double u[N], u_thr, u_th0;
+        int pref = 0;  // tries whose uniforms are in the ring: [.., pref)
+        if (REPLAY) {
+            const bool ok = cursor + d <= a.replay_stride;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int cc = V::comp(g, i);
+                u[i] = (cc < d) ? (ok ? rp[cursor + cc] : 0.5) : 0.0;
+            }
+            if (ok)
+                cursor += d;
+            else {
+                cursor = a.replay_stride;
+                if (alive) err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+            }
+            auto take = [&]() -> double {
+                if (cursor >= a.replay_stride) {
+                    if (alive) err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+                    return 0.5;
+                }
+                return rp[cursor++];
+            };
+            u_thr = take();
+            u_th0 = shrink ? take() : 0.0;
+        } else {
+            dr.begin_step(a.step_offset + (uint64_t)s);
+#pragma unroll
+            for (int iq = 0; iq < Q; ++iq) {
+                const int quad = g + L * iq;
+                const int e = quad - nq;  // lanes past the normals draw block 0 and the first tries' blocks
+                uint32_t w[4];
+                dr.words(e < 0 ? 1u + (uint32_t)quad : (e == 0 ? 0u : try_base + (uint32_t)(e - 1)), w);
+                double z0, z1, z2, z3;
+                box_muller32(w[0], w[1], tab, z0, z1);
+                box_muller32(w[2], w[3], tab, z2, z3);
+                const int c0 = 4 * quad;
+                u[4 * iq + 0] = (c0 < d) ? z0 : 0.0;
+                u[4 * iq + 1] = (c0 + 1 < d) ? z1 : 0.0;
+                u[4 * iq + 2] = (c0 + 2 < d) ? z2 : 0.0;
+                u[4 * iq + 3] = (c0 + 3 < d) ? z3 : 0.0;
+                publish_extra(e, w);
+            }
+            pref = 2 * (L * Q - nq - 1);
+            if (pref < 0) {  // every lane holds normals: block 0 and the first tries take a round of their own
+                uint32_t w[4];
+                dr.words(g == 0 ? 0u : try_base + (uint32_t)(g - 1), w);
+                publish_extra(g, w);
+                pref = 2 * (L - 1);
+            }
+            wave_sync();
+            u_thr = scr[0];
+            u_th0 = scr[1];
+        }
+        // ---------------- u = spherical_projection(z, x)   (sphere.py:29-33)
+        const double rnx = inv_norm(vdot<V>(x, x));
+        const double cz = vdot<V>(u, x) * rnx;
+#pragma unroll
+        for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
+        // ---------------- a_r . u = (a_r . w) / |w|, a_r . x; single-precision pack; the doubles parked for decide()
+        const bool refresh = !kRecur || s == 0 || ((a.step_offset + (uint64_t)s) % kCoefRefresh) == 0;
+        float q[Curve32<NK>::kFloats];
+        {
+            double pw = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
+            const double rnw = inv_norm(group_sum<L>(pw));
+#pragma unroll
+            for (int r = 0; r < NK; ++r) {
+                const double *row = knots + (size_t)r * DPAD;
+                double pu = 0.0, px = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double kv = row[V::comp(g, i)];
+                    pu = fma(kv, u[i], pu);
+                    if (refresh) px = fma(kv, x[i], px);
+                }
+                const double au = group_sum<L>(pu) * rnw;
+                if (refresh) ax[r] = group_sum<L>(px);
+                q[r] = (float)ax[r];
+                q[NK + r] = (float)au;
+                if (g == (r % L)) {
+                    coef[r] = ax[r];
+                    coef[NK + r] = au;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) u[i] *= rnw;
+        }
+        wave_sync();
+        const bool finite = c32s.finish32(u_thr, q);  // threshold and margin (Curve32)
+        if (alive && !finite) {
+            err |= GSSS_CHAIN_NONFINITE;
+            alive = false;
+        }
+        if (REPLAY && (err & GSSS_CHAIN_REPLAY_EXHAUSTED)) alive = false;
+        double lo, hi;
+        if (shrink) {
+            hi = kTwoPi * u_th0;  // mcmc.py:391-392
+            lo = hi - kTwoPi;
+        } else {
+            lo = 0.0;             // mcmc.py:367
+            hi = kTwoPi;
+        }
+        // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397),
+        // FastCurve::level operation for operation, from the parked coefficients, segment by segment in a rolled loop --
+        // this path costs the kernel no registers.
+        auto decide = [&](double theta) -> bool {
+            double sn, cs;
+            fm::sincos_tab(theta, tab, sn, cs);
+            double best0 = -INFINITY, dot0 = 0.0, best1 = -INFINITY, dot1 = 0.0;
+            double cx = coef[0], cu = coef[NK];
+            double ay0 = fma(1.0, cx, 0.0 * cu), ay1 = fma(cs, cx, sn * cu);
+#pragma unroll 1
+            for (int gg = 0; gg + 1 < NK; ++gg) {
+                cx = coef[gg + 1];
+                cu = coef[NK + gg + 1];
+                const double by0 = fma(1.0, cx, 0.0 * cu), by1 = fma(cs, cx, sn * cu);
+                scl.segment(gg, ay0, by0, best0, dot0);
+                scl.segment(gg, ay1, by1, best1, dot1);
+                ay0 = by0;
+                ay1 = by1;
+            }
+            return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
+        };
+
+        // ---------------- batches of L speculative tries
+        bool done = !alive, accepted = false;
+        double th_acc = 0.0;
+        for (int t_base = 0; __any(!done); t_base += L) {
+            if (!done && t_base >= max_tries) {
+                n_try += max_tries;
+                err |= GSSS_CHAIN_MAX_TRIES;
+                done = true;
+            }
+            int valid = L;  // replay: draws available for this batch
+            if (REPLAY) {
+                valid = 0;
+#pragma unroll
+                for (int qq = 0; qq < L; ++qq) {
+                    const bool have = cursor + qq < a.replay_stride;
+                    ring[qq] = have ? rp[cursor + qq] : 0.5;
+                    valid += have ? 1 : 0;
+                }
+                wave_sync();
+            } else {
+                while (t_base + L > pref) {  // (wave-uniform) another round: lane g draws the tries' block pref / 2 + g
+                    uint32_t w[4];
+                    dr.words(try_base + (uint32_t)(pref >> 1) + (uint32_t)g, w);
+                    publish_extra(1 + (pref >> 1) + g, w);
+                    pref += 2 * L;
+                    wave_sync();
+                }
+            }
+            double my_theta = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < L; ++qq) {
+                const double ut = REPLAY ? ring[qq] : ring[(t_base + qq) & (kRing - 1)];
+                const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
+                if (g == qq) my_theta = theta;
+                if (shrink) {                               // mcmc.py:400, assuming try qq is rejected
+                    if (theta < 0.0)
+                        lo = theta;
+                    else
+                        hi = theta;
+                }
+            }
+            if (REPLAY) wave_sync();  // the ring is rewritten by the next batch
+            float s32, c32f;
+            sincos_rev32(my_theta, s32, c32f);
+            const bool mine = !done && g < valid && t_base + g < max_tries;
+            int verdict = mine ? c32s.screen(q, c32f, s32) : -1;
+            // first try of the group that is not certainly rejected; an undecided one is decided in double precision by its lane
+            int T = L;
+            for (;;) {
+                const unsigned long long open = __ballot(verdict >= 0);
+                const unsigned gm = (unsigned)(open >> base) & ((1u << L) - 1u);
+                T = gm ? __builtin_ctz(gm) : L;
+                const bool need = g == T && verdict == 0;
+                if (!__any(need)) break;
+                if (need) verdict = decide(my_theta) ? 1 : -1;
+            }
+            const double th_T = __shfl(my_theta, base + (T < L ? T : 0));
+            if (!done) {
+                if (T < L) {
+                    accepted = true;
+                    done = true;
+                    th_acc = th_T;
+                    n_try += t_base + T + 1;
+                    if (REPLAY) cursor += T + 1;
+                } else {
+                    if (REPLAY) {
+                        cursor += valid;
+                        if (valid < L) {
+                            n_try += t_base + valid;
+                            err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
+                            done = true;
+                        }
+                    }
+                    if (!done && max_tries - t_base <= L) {
+                        n_try += max_tries;
+                        err |= GSSS_CHAIN_MAX_TRIES;
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (alive && !accepted) alive = false;  // (an error flag is set)
+        // ---------------- move (mcmc.py:396)
+        double sn, cs;
+        fm::sincos_tab(th_acc, tab, sn, cs);
+        if (alive) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
+            if (kRecur) {
+#pragma unroll
+                for (int r = 0; r < NK; ++r) ax[r] = fma(cs, ax[r], sn * coef[NK + r]);  // a . x' = c a.x + s a.u
+            }
+            ++steps_done;
+            if (a.samples != nullptr && --until_keep == 0) {
+                until_keep = (int32_t)a.thin;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const int cc = V::comp(g, i);
+                    if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
+                }
+                ++row_out;
+            }
+        }
+        if (kRecur) wave_sync();  // coef is rewritten by the next step
+    }
+
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cc = V::comp(g, i);
+            if (cc < d) a.state[(size_t)cc * n + c] = x[i];
+        }
+        if (g == 0) {
+            if (a.n_reject) a.n_reject[c] += n_try - steps_done;
+            if (a.n_tries) a.n_tries[c] += n_try;
+            if (a.err && err) a.err[c] |= err;
+        }
+    }
+}
+
+template <int L, int Q, int NK>
+int do_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
+{
+    if (rb.rng_state != nullptr) {
+        set_error("in fast mode the numpy stream is served by the one-wavefront-per-chain kernel only; use GSSS_MODE_EXACT");
+        return GSSS_E_UNSUPPORTED;
+    }
+    if (tb.d > 4 * Q * L || tb.k > NK || tb.k < 2) {
+        set_error("curvespec kernel <%d, %d, %d> cannot hold d=%d, %d knots", L, Q, NK, tb.d, tb.k);
+        return GSSS_E_UNSUPPORTED;
+    }
+    const size_t lds = curvespec_lds_doubles<L, Q, NK>() * sizeof(double);
+    auto kern = replay ? curvespec_kernel<L, Q, NK, true> : curvespec_kernel<L, Q, NK, false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GSSS_E_HIP;
+        }
+    }
+    const int64_t per_block = kBlock / L;
+    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("curvespec kernel launch failed: %s", hipGetErrorString(e));
+        return GSSS_E_HIP;
+    }
+    return GSSS_OK;
+}
+
+}  // namespace gsss

@@ -276,6 +276,25 @@ struct FastCurve {
     {
         return level(cf, c, s);
     }
+    // one segment (a, b) of the curve given a.y and b.y: keeps the first maximum of the clipped y . nearest
+    __device__ __forceinline__ void segment(int g, double ay, double by, double &best, double &best_dot) const
+    {
+        const double ct = seg[4 * g], st = seg[4 * g + 1], rden = seg[4 * g + 2];
+        const double A = ay * st;
+        const double B = fma(-ay, ct, by);
+        const double h2 = fma(A, A, B * B);
+        const double rh = h2 > 0.0 ? rsqrt(h2) : 0.0;
+        const double inner = fma(fma(st, A, -ct * B), ay, B * by) * rh;  // sin(th-t) a.y + sin(t) b.y
+        const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
+        const bool at_b = A * rh < ct;
+        const double num = at_a ? st * ay : (at_b ? st * by : inner);
+        const double xy = num * rden;
+        const double xc = fmin(fmax(xy, -1.0), 1.0);
+        if (g < nseg && xc > best) {
+            best = xc;
+            best_dot = xy;
+        }
+    }
     __device__ __forceinline__ double level(const Coef &cf, double c, double s) const
     {
         double best = -INFINITY, best_dot = 0.0;
@@ -283,22 +302,23 @@ struct FastCurve {
 #pragma unroll
         for (int g = 0; g + 1 < NK; ++g) {
             const double by = fma(c, cf.ax[g + 1], s * cf.au[g + 1]);
-            const double ct = seg[4 * g], st = seg[4 * g + 1], rden = seg[4 * g + 2];
-            const double A = ay * st;
-            const double B = fma(-ay, ct, by);
-            const double h2 = fma(A, A, B * B);
-            const double rh = h2 > 0.0 ? rsqrt(h2) : 0.0;
-            const double inner = fma(fma(st, A, -ct * B), ay, B * by) * rh;  // sin(th-t) a.y + sin(t) b.y
-            const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
-            const bool at_b = A * rh < ct;
-            const double num = at_a ? st * ay : (at_b ? st * by : inner);
-            const double xy = num * rden;
-            const double xc = fmin(fmax(xy, -1.0), 1.0);
-            if (g < nseg && xc > best) {
-                best = xc;
-                best_dot = xy;
-            }
+            segment(g, ay, by, best, best_dot);
             ay = by;
+        }
+        return kappa * best_dot;
+    }
+    // level() one segment after the other (the rare double-precision decisions of the screened kernels: left alone the
+    // scheduler interleaves all segments and holds their constants and intermediates in ~100 registers)
+    __device__ __forceinline__ double level_serial(const Coef &cf, double c, double s) const
+    {
+        double best = -INFINITY, best_dot = 0.0;
+        double ay = fma(c, cf.ax[0], s * cf.au[0]);
+#pragma unroll
+        for (int g = 0; g + 1 < NK; ++g) {
+            const double by = fma(c, cf.ax[g + 1], s * cf.au[g + 1]);
+            segment(g, ay, by, best, best_dot);
+            ay = by;
+            __builtin_amdgcn_sched_barrier(0);
         }
         return kappa * best_dot;
     }
@@ -714,6 +734,7 @@ struct FastProbe {
 int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st);
 int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st);
 int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st);
+int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, bool lane, hipStream_t st);
 #define GSSS_PROBE(LANE, ...)                                         \
     do {                                                              \
         snprintf(probe->name, sizeof(probe->name), __VA_ARGS__);      \

@@ -9,9 +9,12 @@ namespace gsss {
 
 int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
 {
+    const bool spec = rb.screen && !rb.spread && rb.rng_state == nullptr && rb.stats == nullptr && tb.k >= 2 && tb.k <= 17 &&
+                      tb.d >= 9 && tb.d <= 256;
     // lane-per-chain kernels: the listed dimensions, any curve of 2 .. 10 knots (built for 10; FastCurve pads)
 #define GSSS_CASE(D)                                                \
     if (tb.d == D && tb.k >= 2 && tb.k <= 10) {                     \
+        if (spec) return launch_curvespec(tb, rb, replay, probe, true, st); \
         const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr; \
         if (probe) {                                                \
             if (rb.screen) GSSS_PROBE(true, "screened_kernel<%d, ScreenCurve<%d, 10>>", D, D); \
@@ -22,6 +25,7 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, Fa
     }
     GSSS_FAST_CURVE_DIMS(GSSS_CASE)
 #undef GSSS_CASE
+    if (spec) return launch_curvespec(tb, rb, replay, probe, false, st);
     // 64 < d <= 256, up to 17 knots: one chain per wavefront, four speculative tries per iteration
     if (tb.d > 64 && tb.d <= 256 && tb.k >= 2 && tb.k <= 17) {
         if (probe) GSSS_PROBE(false, "curve64_kernel<%d>", tb.k <= 11 ? 12 : 20);

@@ -60,6 +60,9 @@ __device__ __forceinline__ float log2_32(double v)
 //   screen(q, c, s)            -1 reject / +1 accept (both certain) / 0 undecided
 //   threshold(cf, x, u, U)     the double-precision threshold exactly as fast_kernel forms it (undecided tries only)
 //   level_exact(cf, c, s)      the double-precision level fast_kernel compares with that threshold
+// and the two fused forms the kernel calls (a target may build them without ever holding a whole Coef in registers):
+//   setup32(x, u, U, q)        = coeffs + make32
+//   decide(x, u, U, c, s)      = level_exact(c, s) > threshold, the all-double decision of an undecided try
 // ------------------------------------------------------------------------------------------
 template <int D, int KC>
 struct ScreenVmf : FastVmf<D, KC> {
@@ -141,6 +144,18 @@ struct ScreenVmf : FastVmf<D, KC> {
         for (int k = 0; k < KC; ++k) a[k] = fma(c, cf.ax[k], fma(s, cf.au[k], this->logc[k])) - cf.m;
         return this->level_full(a);
     }
+    __device__ __forceinline__ bool setup32(const double (&x)[D], const double (&u)[D], double u_thr, float (&q)[kCoef32Floats]) const
+    {
+        Coef cf;
+        coeffs(cf, x, u);
+        return make32(cf, u_thr, q);
+    }
+    __device__ __forceinline__ bool decide(const double (&x)[D], const double (&u)[D], double u_thr, double c, double s) const
+    {
+        Coef cf;
+        const double thr = threshold(cf, x, u, u_thr);
+        return level_exact(cf, c, s) > thr;
+    }
 };
 
 // Bingham / BinghamFisher: log-density q(theta) = c^2 qxx + c s qxu + s^2 quu + c bx + s bu (distributions.py:86, :113-114),
@@ -181,6 +196,90 @@ struct ScreenBingham : FastBingham<D> {
         return this->make(cf, x, u, 0.0, true) + fm::log_fast(u_thr);
     }
     __device__ __forceinline__ double level_exact(const Coef &cf, double c, double s) const { return this->level(cf, c, s); }
+    __device__ __forceinline__ bool setup32(const double (&x)[D], const double (&u)[D], double u_thr, float (&q)[kCoef32Floats]) const
+    {
+        Coef cf;
+        coeffs(cf, x, u);
+        return make32(cf, u_thr, q);
+    }
+    __device__ __forceinline__ bool decide(const double (&x)[D], const double (&u)[D], double u_thr, double c, double s) const
+    {
+        Coef cf;
+        const double thr = threshold(cf, x, u, u_thr);
+        return level_exact(cf, c, s) > thr;
+    }
+};
+
+// The single-precision side of the curve-vMF screen, independent of how the chain's components are laid out
+// (lane kernels: ScreenCurve below; lane groups: gsss_curvespec.h).  q = [a_i.x | a_i.u | thr / kappa | margin].
+template <int NK>
+struct Curve32 {
+    const float4 *seg32;  // LDS [NK-1]: cos, sin, 1 / (sin + 1e-10) per segment in single precision (read as one broadcast b128)
+    float inv_sin_min;
+    int nseg;
+    double kappa;
+    static constexpr int kFloats = 2 * NK + 2;
+    // max over the segments of the clipped y . nearest, single precision
+    __device__ __forceinline__ float best32(const float (&q)[kFloats], float c, float s) const
+    {
+        float best = -INFINITY;
+        float ay = fmaf(c, q[0], s * q[NK]);
+#pragma unroll
+        for (int g = 0; g + 1 < NK; ++g) {
+            const float by = fmaf(c, q[g + 1], s * q[NK + g + 1]);
+            const float4 sg = seg32[g];
+            const float ct = sg.x, st = sg.y, rden = sg.z;
+            const float A = ay * st;
+            const float B = fmaf(-ay, ct, by);
+            const float h2 = fmaf(A, A, B * B);
+            const float rh = h2 > 0.0f ? __builtin_amdgcn_rsqf(h2) : 0.0f;
+            const bool at_a = B < 0.0f || (B == 0.0f && A >= 0.0f);
+            const bool at_b = A * rh < ct;
+            const float num = at_a ? st * ay : (at_b ? st * by : h2 * rh);
+            if (g < nseg) best = fmaxf(best, fminf(fmaxf(num * rden, -1.0f), 1.0f));
+            ay = by;
+        }
+        return best;
+    }
+    // margin and threshold from the rounded coefficients q[0 .. 2 NK); false if the level of x is not finite
+    __device__ __forceinline__ bool finish32(double u_thr, float (&q)[kFloats]) const
+    {
+        float b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) b = fmaxf(b, fabsf(q[i]) + fabsf(q[NK + i]));
+        // error of a.y: (|a.x| + |a.u|) (eps + 2^-24) + the fma roundings
+        const float delta = b * (kSinCosErr32 + 3.0f * kUnit32);
+        // one evaluation: 3 delta Lipschitz + ~16 roundings of values <= 2, all over sin(theta_g); v_rsq_f32 relative 2^-22
+        const float e_eval = (3.0f * delta + 40.0f * kUnit32) * inv_sin_min * 1.05f;
+        // thr / kappa = level32(x) / kappa + log(U) / kappa: the level of x is evaluated by the same routine at theta = 0
+        const float lvl0 = best32(q, 1.0f, 0.0f);
+        const double tau = (double)lvl0 + fm::log_fast(u_thr) / kappa;
+        q[2 * NK] = (float)tau;
+        float margin = 1.25f * (2.0f * e_eval + kUnit32 * (fabsf(q[2 * NK]) + 1.0f));
+        if (!(u_thr > 1e-290) || !(margin < 0.25f)) margin = INFINITY;
+        q[2 * NK + 1] = margin;
+        return lvl0 >= -1.0f && lvl0 <= 1.0f;  // (NaN fails)
+    }
+    __device__ __forceinline__ int screen(const float (&q)[kFloats], float c, float s) const
+    {
+        const float g = best32(q, c, s) - q[2 * NK];
+        return g < -q[2 * NK + 1] ? -1 : (g > q[2 * NK + 1] ? 1 : 0);
+    }
+    // stages the single-precision segment constants from the double-precision ones seg[NK-1][4] (cos, sin, 1 / (sin + 1e-10));
+    // the caller synchronises before (seg complete) and after
+    __device__ void stage(float4 *s32, const double *seg, int nseg_, double kappa_)
+    {
+        for (int g = threadIdx.x; g < NK - 1; g += kBlock)
+            s32[g] = make_float4((float)seg[4 * g], (float)seg[4 * g + 1], (float)seg[4 * g + 2], 0.0f);
+        seg32 = s32;
+        nseg = nseg_;
+        kappa = kappa_;
+        float m = 0.0f;
+#pragma unroll
+        for (int g = 0; g + 1 < NK; ++g)
+            if (g < nseg_) m = fmaxf(m, fabsf((float)seg[4 * g + 2]));
+        inv_sin_min = m;
+    }
 };
 
 // curve-vMF: level = kappa * max_g clip(y . nearest point of segment g) (FastCurve).  In units of the dot product the
@@ -192,22 +291,13 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Base = FastCurve<D, NK>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
-    const float4 *seg32;  // LDS [NK-1]: cos, sin, 1 / (sin + 1e-10) per segment in single precision (read as one broadcast b128)
-    float inv_sin_min;
+    Curve32<NK> c32;
     __host__ __device__ static size_t lds_doubles() { return Base::lds_doubles() + 2 * (size_t)(NK - 1); }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         Base::stage(lds, tb);
         __syncthreads();
-        float4 *s32 = reinterpret_cast<float4 *>(lds + Base::lds_doubles());
-        for (int g = threadIdx.x; g < NK - 1; g += kBlock)
-            s32[g] = make_float4((float)this->seg[4 * g], (float)this->seg[4 * g + 1], (float)this->seg[4 * g + 2], 0.0f);
-        seg32 = s32;
-        float m = 0.0f;
-#pragma unroll
-        for (int g = 0; g + 1 < NK; ++g)
-            if (g < this->nseg) m = fmaxf(m, fabsf((float)this->seg[4 * g + 2]));
-        inv_sin_min = m;
+        c32.stage(reinterpret_cast<float4 *>(lds + Base::lds_doubles()), this->seg, this->nseg, this->kappa);
     }
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
@@ -226,60 +316,67 @@ struct ScreenCurve : FastCurve<D, NK> {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // max over the segments of the clipped y . nearest, single precision
-    __device__ __forceinline__ float best32(const float (&q)[kCoef32Floats], float c, float s) const
-    {
-        float best = -INFINITY;
-        float ay = fmaf(c, q[0], s * q[NK]);
-#pragma unroll
-        for (int g = 0; g + 1 < NK; ++g) {
-            const float by = fmaf(c, q[g + 1], s * q[NK + g + 1]);
-            const float4 sg = seg32[g];
-            const float ct = sg.x, st = sg.y, rden = sg.z;
-            const float A = ay * st;
-            const float B = fmaf(-ay, ct, by);
-            const float h2 = fmaf(A, A, B * B);
-            const float rh = h2 > 0.0f ? __builtin_amdgcn_rsqf(h2) : 0.0f;
-            const bool at_a = B < 0.0f || (B == 0.0f && A >= 0.0f);
-            const bool at_b = A * rh < ct;
-            const float num = at_a ? st * ay : (at_b ? st * by : h2 * rh);
-            if (g < this->nseg) best = fmaxf(best, fminf(fmaxf(num * rden, -1.0f), 1.0f));
-            ay = by;
-        }
-        return best;
-    }
     __device__ __forceinline__ bool make32(const Coef &cf, double u_thr, float (&q)[kCoef32Floats]) const
     {
-        float b = 0.0f;
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
             q[i] = (float)cf.ax[i];
             q[NK + i] = (float)cf.au[i];
-            b = fmaxf(b, fabsf(q[i]) + fabsf(q[NK + i]));
         }
-        // error of a.y: (|a.x| + |a.u|) (eps + 2^-24) + the fma roundings
-        const float delta = b * (kSinCosErr32 + 3.0f * kUnit32);
-        // one evaluation: 3 delta Lipschitz + ~16 roundings of values <= 2, all over sin(theta_g); v_rsq_f32 relative 2^-22
-        const float e_eval = (3.0f * delta + 40.0f * kUnit32) * inv_sin_min * 1.05f;
-        // thr / kappa = level32(x) / kappa + log(U) / kappa: the level of x is evaluated by the same routine at theta = 0
-        const float lvl0 = best32(q, 1.0f, 0.0f);
-        const double tau = (double)lvl0 + fm::log_fast(u_thr) / this->kappa;
-        q[2 * NK] = (float)tau;
-        float margin = 1.25f * (2.0f * e_eval + kUnit32 * (fabsf(q[2 * NK]) + 1.0f));
-        if (!(u_thr > 1e-290) || !(margin < 0.25f)) margin = INFINITY;
-        q[2 * NK + 1] = margin;
-        return lvl0 >= -1.0f && lvl0 <= 1.0f;  // (NaN fails)
+        return finish32(u_thr, q);
     }
-    __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const
-    {
-        const float g = best32(q, c, s) - q[2 * NK];
-        return g < -q[2 * NK + 1] ? -1 : (g > q[2 * NK + 1] ? 1 : 0);
-    }
+    __device__ __forceinline__ bool finish32(double u_thr, float (&q)[kCoef32Floats]) const { return c32.finish32(u_thr, q); }
+    __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const { return c32.screen(q, c, s); }
     __device__ __forceinline__ double threshold(Coef &cf, const double (&x)[D], const double (&u)[D], double u_thr) const
     {
         return this->make(cf, x, u, 0.0, true) + fm::log_fast(u_thr);
     }
     __device__ __forceinline__ double level_exact(const Coef &cf, double c, double s) const { return this->level(cf, c, s); }
+    // The fused forms never hold the 2 NK double-precision coefficients at once (80 registers at NK = 10): a knot's two
+    // dots are rounded into the single-precision pack, or fed to the segment algebra, as soon as they are formed.
+    __device__ __forceinline__ bool setup32(const double (&x)[D], const double (&u)[D], double u_thr, float (&q)[kCoef32Floats]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            double ax = 0.0, au = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double kij = this->knots[i * D + j];
+                ax = fma(kij, x[j], ax);
+                au = fma(kij, u[j], au);
+            }
+            q[i] = (float)ax;
+            q[NK + i] = (float)au;
+            __builtin_amdgcn_sched_barrier(0);  // one knot at a time (see coeffs)
+        }
+        return finish32(u_thr, q);
+    }
+    // FastCurve::make followed by level(cf, 1, 0) and level(cf, c, s), operation for operation, knot by knot
+    __device__ __forceinline__ bool decide(const double (&x)[D], const double (&u)[D], double u_thr, double c, double s) const
+    {
+        double best0 = -INFINITY, dot0 = 0.0, best1 = -INFINITY, dot1 = 0.0;
+        double ay0 = 0.0, ay1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            double ax = 0.0, au = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double kij = this->knots[i * D + j];
+                ax = fma(kij, x[j], ax);
+                au = fma(kij, u[j], au);
+            }
+            const double by0 = fma(1.0, ax, 0.0 * au);
+            const double by1 = fma(c, ax, s * au);
+            if (i > 0) {
+                this->segment(i - 1, ay0, by0, best0, dot0);
+                this->segment(i - 1, ay1, by1, best1, dot1);
+            }
+            ay0 = by0;
+            ay1 = by1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return this->kappa * dot1 > this->kappa * dot0 + fm::log_fast(u_thr);
+    }
 };
 
 template <int D, class TP>
@@ -421,10 +518,8 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
 #pragma unroll
             for (int j = 0; j < D; ++j) cur.u[j] *= rnw;
         }
-        Coef cf;
-        tp.coeffs(cf, cur.x, cur.u);
         cur.thr = u_thr;  // the uniform; the double-precision threshold is formed only if a try stays undecided
-        const bool finite = tp.make32(cf, u_thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
+        const bool finite = tp.setup32(cur.x, cur.u, u_thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
         if (shrink) {
             cur.hi = kTwoPi * u_th0;
             cur.lo = cur.hi - kTwoPi;
@@ -494,9 +589,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         fm::sincos_tab(theta, tab, sn, cs);
         bool accepted = true;
         if (cur.status == kFinalDecide) {  // rare: the double-precision test itself (mcmc.py:389, 397)
-            Coef cf;
-            const double thr = tp.threshold(cf, cur.x, cur.u, cur.thr);
-            accepted = tp.level_exact(cf, cs, sn) > thr;
+            accepted = tp.decide(cur.x, cur.u, cur.thr, cs, sn);
         }
         if (accepted) {
 #pragma unroll
