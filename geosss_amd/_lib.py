@@ -10,6 +10,7 @@ VMF_MIXTURE, BINGHAM, CURVE_VMF, CPD = 1, 2, 3, 4
 SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
 MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
+VARIANT_FAST_VERIFY = 101
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
 ABI_VERSION = 6
 

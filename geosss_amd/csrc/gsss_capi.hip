@@ -505,8 +505,8 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("replay_stride must be >= 1");
         return GSSS_E_INVALID;
     }
-    if (a->mode == GSSS_MODE_FAST && a->variant != 0 && a->variant != GSSS_VARIANT_FAST_DOUBLE) {
-        set_error("fast mode takes variant 0 or GSSS_VARIANT_FAST_DOUBLE");
+    if (a->mode == GSSS_MODE_FAST && a->variant != 0 && a->variant != GSSS_VARIANT_FAST_DOUBLE && a->variant != GSSS_VARIANT_FAST_VERIFY) {
+        set_error("fast mode takes variant 0, GSSS_VARIANT_FAST_DOUBLE or GSSS_VARIANT_FAST_VERIFY");
         return GSSS_E_INVALID;
     }
     const int vec = a->mode == GSSS_MODE_FAST ? 0 : select_vec(t->tb.d, a->variant);
@@ -534,7 +534,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         return GSSS_E_INVALID;
     }
     rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= 2048) ? 1 : 0;
-    rb.screen = (a->mode == GSSS_MODE_FAST && a->variant == GSSS_VARIANT_FAST_DOUBLE) ? 0 : 1;
+    rb.screen = (a->mode == GSSS_MODE_FAST && a->variant == GSSS_VARIANT_FAST_DOUBLE) ? 0 : (a->variant == GSSS_VARIANT_FAST_VERIFY ? 2 : 1);
     rb.stats = a->stats_dev;
     rb.stats_dirs = a->stats_dirs_dev;
     rb.stats_lags = a->stats_lags;

@@ -30,6 +30,15 @@
 
 namespace gsss {
 
+// wavefronts per SIMD asked of the compiler (Q <= 2 / larger).  Measured on MI355X, d = 10 / 50 / 200, ms per 10^8 chain-steps:
+// 2: 43.7 / 81.1 / 154;  3: 34.7 / 66.1 / 245;  4 (28 registers spilled): 31.7 / 63.0
+#ifndef GSSS_CS_WAVES
+#define GSSS_CS_WAVES 4
+#endif
+#ifndef GSSS_CS_WAVES_BIG
+#define GSSS_CS_WAVES_BIG 2
+#endif
+
 template <int L, int NK>
 __host__ __device__ constexpr int curvespec_scratch_doubles()
 {
@@ -42,8 +51,34 @@ __host__ __device__ constexpr size_t curvespec_lds_doubles()
            (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2;
 }
 
+// The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397),
+// FastCurve::level operation for operation, from the step's coefficients parked in LDS (coef[0 .. NK) = a_i.x,
+// coef[NK .. 2 NK) = a_i.u), segment by segment in a rolled loop.  (Inlined on purpose: as a called function it takes the
+// tables and segment constants through generic pointers, and every table read of the kernel becomes a flat_load.)
+template <int NK>
+__device__ __forceinline__ bool curvespec_decide(const FastCurve<1, NK> &scl, const double *coef, const fm::Tables &tab, double theta,
+                                              double u_thr)
+{
+    double sn, cs;
+    fm::sincos_tab(theta, tab, sn, cs);
+    double best0 = -INFINITY, dot0 = 0.0, best1 = -INFINITY, dot1 = 0.0;
+    double cx = coef[0], cu = coef[NK];
+    double ay0 = fma(1.0, cx, 0.0 * cu), ay1 = fma(cs, cx, sn * cu);
+#pragma unroll 1
+    for (int gg = 0; gg + 1 < NK; ++gg) {
+        cx = coef[gg + 1];
+        cu = coef[NK + gg + 1];
+        const double by0 = fma(1.0, cx, 0.0 * cu), by1 = fma(cs, cx, sn * cu);
+        scl.segment(gg, ay0, by0, best0, dot0);
+        scl.segment(gg, ay1, by1, best1, dot1);
+        ay0 = by0;
+        ay1 = by1;
+    }
+    return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
+}
+
 template <int L, int Q, int NK, bool REPLAY>
-__global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, Q <= 2 ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
     using V = CoopVec<L, 4 * Q>;
     using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level
@@ -104,9 +139,8 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
     const double *rp = REPLAY ? a.replay + (size_t)c * a.replay_stride : nullptr;
     int64_t cursor = 0;
     int err = 0;
-    double ax[NK];  // a_i . x (kRecur: carried from step to step)
-#pragma unroll
-    for (int r = 0; r < NK; ++r) ax[r] = 0.0;
+    // (kRecur: a_i . x is carried from step to step in the group's LDS words coef[0 .. NK), advanced by lane 0)
+    float lvl_c = 0.0f, e_c = 0.0f;  // single-precision level of the accepted point and its error bound, carried to the next step
     int64_t n_try = 0;
     int32_t steps_done = 0, until_keep = (int32_t)a.thin, row_out = 0;
     bool alive = active && a.n_steps > 0;
@@ -133,8 +167,9 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
         if (!__any(alive)) break;
         // The target's constants never change, so the compiler would hoist their LDS loads out of this loop and keep them
         // in registers for the whole launch: the base is made opaque once per step.
-        const double *knots = lds;
-        asm volatile("" : "+s"(knots));
+        unsigned opaque = 0u;
+        asm volatile("" : "+s"(opaque));
+        const double *knots = lds + opaque;  // (an offset, so that the pointer stays an LDS pointer: ds_read, not flat_load)
         Scalar scl = sc;
         scl.seg = knots + (size_t)NK * DPAD;
         Curve32<NK> c32s = c32;
@@ -181,6 +216,7 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
                 u[4 * iq + 2] = (c0 + 2 < d) ? z2 : 0.0;
                 u[4 * iq + 3] = (c0 + 3 < d) ? z3 : 0.0;
                 publish_extra(e, w);
+                if (Q > 1) __builtin_amdgcn_sched_barrier(0);  // one round at a time
             }
             pref = 2 * (L * Q - nq - 1);
             if (pref < 0) {  // every lane holds normals: block 0 and the first tries take a round of their own
@@ -206,6 +242,10 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
             const double rnw = inv_norm(group_sum<L>(pw));
+            constexpr int kParked = (NK + L - 1) / L;
+            double park_u[kParked], park_x[kParked];
+#pragma unroll
+            for (int j = 0; j < kParked; ++j) park_u[j] = park_x[j] = 0.0;
 #pragma unroll
             for (int r = 0; r < NK; ++r) {
                 const double *row = knots + (size_t)r * DPAD;
@@ -217,19 +257,42 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
                     if (refresh) px = fma(kv, x[i], px);
                 }
                 const double au = group_sum<L>(pu) * rnw;
-                if (refresh) ax[r] = group_sum<L>(px);
-                q[r] = (float)ax[r];
+                const double axr = refresh ? group_sum<L>(px) : coef[r];
+                q[r] = (float)axr;
                 q[NK + r] = (float)au;
-                if (g == (r % L)) {
-                    coef[r] = ax[r];
-                    coef[NK + r] = au;
+                if (g == r % L) {  // lane r mod L parks knot r's pair for decide() and the recurrence (a select here, one store below)
+                    park_u[r / L] = au;
+                    park_x[r / L] = axr;
+                }
+                // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
+                if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < kParked; ++j) {
+                const int r = g + L * j;
+                if (r < NK) {
+                    coef[NK + r] = park_u[j];
+                    if (refresh) coef[r] = park_x[j];
                 }
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) u[i] *= rnw;
         }
         wave_sync();
-        const bool finite = c32s.finish32(u_thr, q);  // threshold and margin (Curve32)
+        // threshold and margin (Curve32).  The level of x in single precision: the value the accepted try of the previous
+        // step was screened with (it is within that step's evaluation error of the double-precision level of y(theta_T), which
+        // IS the level of x now: the same operations on the same coefficients under the recurrence, and within ~1e-15 of
+        // it where a_i.x is formed from x again) -- or the screen's own evaluation at theta = 0 after a refresh.
+        float e_eval;
+        bool finite;
+        if (refresh && kRecur || s == 0) {
+            finite = c32s.finish32(u_thr, q);
+            e_eval = c32s.eval_error(q);
+        } else {
+            finite = c32s.finish32_carried(u_thr, q, lvl_c, e_c + 1.0e-12f, e_eval);
+        }
+        e_c = e_eval;
+        if (a.screen == 2) q[2 * NK + 1] = INFINITY;  // verification: every try is left to the double-precision decision
         if (alive && !finite) {
             err |= GSSS_CHAIN_NONFINITE;
             alive = false;
@@ -243,27 +306,7 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
             lo = 0.0;             // mcmc.py:367
             hi = kTwoPi;
         }
-        // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397),
-        // FastCurve::level operation for operation, from the parked coefficients, segment by segment in a rolled loop --
-        // this path costs the kernel no registers.
-        auto decide = [&](double theta) -> bool {
-            double sn, cs;
-            fm::sincos_tab(theta, tab, sn, cs);
-            double best0 = -INFINITY, dot0 = 0.0, best1 = -INFINITY, dot1 = 0.0;
-            double cx = coef[0], cu = coef[NK];
-            double ay0 = fma(1.0, cx, 0.0 * cu), ay1 = fma(cs, cx, sn * cu);
-#pragma unroll 1
-            for (int gg = 0; gg + 1 < NK; ++gg) {
-                cx = coef[gg + 1];
-                cu = coef[NK + gg + 1];
-                const double by0 = fma(1.0, cx, 0.0 * cu), by1 = fma(cs, cx, sn * cu);
-                scl.segment(gg, ay0, by0, best0, dot0);
-                scl.segment(gg, ay1, by1, best1, dot1);
-                ay0 = by0;
-                ay1 = by1;
-            }
-            return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
-        };
+        auto decide = [&](double theta) -> bool { return curvespec_decide<NK>(scl, coef, tab, theta, u_thr); };
 
         // ---------------- batches of L speculative tries
         bool done = !alive, accepted = false;
@@ -310,7 +353,9 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
             float s32, c32f;
             sincos_rev32(my_theta, s32, c32f);
             const bool mine = !done && g < valid && t_base + g < max_tries;
-            int verdict = mine ? c32s.screen(q, c32f, s32) : -1;
+            const float my_b = c32s.best32(q, c32f, s32);
+            const float gap = my_b - q[2 * NK];
+            int verdict = mine ? (gap < -q[2 * NK + 1] ? -1 : (gap > q[2 * NK + 1] ? 1 : 0)) : -1;
             // first try of the group that is not certainly rejected; an undecided one is decided in double precision by its lane
             int T = L;
             for (;;) {
@@ -322,11 +367,13 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
                 if (need) verdict = decide(my_theta) ? 1 : -1;
             }
             const double th_T = __shfl(my_theta, base + (T < L ? T : 0));
+            const float b_T = __shfl(my_b, base + (T < L ? T : 0));
             if (!done) {
                 if (T < L) {
                     accepted = true;
                     done = true;
                     th_acc = th_T;
+                    lvl_c = b_T;
                     n_try += t_base + T + 1;
                     if (REPLAY) cursor += T + 1;
                 } else {
@@ -353,9 +400,9 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? 3 : 2) curvespec_kernel(Targe
         if (alive) {
 #pragma unroll
             for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
-            if (kRecur) {
+            if (kRecur && g == 0) {
 #pragma unroll
-                for (int r = 0; r < NK; ++r) ax[r] = fma(cs, ax[r], sn * coef[NK + r]);  // a . x' = c a.x + s a.u
+                for (int r = 0; r < NK; ++r) coef[r] = fma(cs, coef[r], sn * coef[NK + r]);  // a . x' = c a.x + s a.u
             }
             ++steps_done;
             if (a.samples != nullptr && --until_keep == 0) {

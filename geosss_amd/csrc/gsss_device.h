@@ -45,6 +45,7 @@ struct RunBlock {
     int64_t keep_rows;  // > 0: samples are written chain-major [chain][keep_rows][d]; 0: [row][d][chain]
     int32_t spread;     // lane layouts: one chain per WAVEFRONT (small ensembles: no divergence between chains)
     int32_t screen;     // fast mode: tries are screened in single precision where the target's kernel is built for it
+                        // (2: verification -- the screen's verdicts are ignored by the kernels that can, see gsss.h)
     double *stats;             // NULL or [gsss_stats_rows][n_chains] running statistics of the retained series
     const double *stats_dirs;  // [2 + stats_modes][d]: projection w, hop direction h, mode directions
     int32_t stats_lags, stats_modes;
@@ -189,7 +190,9 @@ __device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, const fm:
 constexpr int kTabLds = fm::kTableDoubles + 2;
 __device__ __forceinline__ fm::Tables stage_tables(double *lds_after_params)
 {
-    double *buf = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(lds_after_params) + 15) & ~(uintptr_t)15);
+    // one double further if that is what 16-byte alignment takes.  (Pointer + integer: rounding the pointer's integer value
+    // up and casting back makes it a generic pointer, and every table read of the kernel a flat_load instead of a ds_read.)
+    double *buf = lds_after_params + ((reinterpret_cast<uintptr_t>(lds_after_params) >> 3) & 1u);
     for (int i = threadIdx.x; i < 64 + fm::kLogTableN; i += kBlock) fm::table_entry(buf, i);
     return fm::Tables{buf, buf + 128};
 }
@@ -226,14 +229,16 @@ constexpr int kDppMirror = 0x140;      // lane i <-> 15-i within 16
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    // (bound_ctrl on: every lane of these permutations has a source, and the destination then needs no prior value --
+    // with it off the compiler zeroes the destination pair before every move)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_move(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 __device__ __forceinline__ double lane_broadcast(double v, int lane)
 {

@@ -216,6 +216,7 @@ template <int NK>
 struct Curve32 {
     const float4 *seg32;  // LDS [NK-1]: cos, sin, 1 / (sin + 1e-10) per segment in single precision (read as one broadcast b128)
     float inv_sin_min;
+    float ln2_over_kappa;
     int nseg;
     double kappa;
     static constexpr int kFloats = 2 * NK + 2;
@@ -240,6 +241,33 @@ struct Curve32 {
             ay = by;
         }
         return best;
+    }
+    // error bound of one best32 evaluation with the coefficients q[0 .. 2 NK)
+    __device__ __forceinline__ float eval_error(const float (&q)[kFloats]) const
+    {
+        float b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) b = fmaxf(b, fabsf(q[i]) + fabsf(q[NK + i]));
+        const float delta = b * (kSinCosErr32 + 3.0f * kUnit32);                // error of a.y
+        return (3.0f * delta + 40.0f * kUnit32) * inv_sin_min * 1.05f;          // see finish32
+    }
+    // finish32 with the single-precision level of x supplied by the caller (lvl0: within e_lvl0 of the double-precision
+    // level of x over kappa -- e.g. the value best32 gave for the accepted try of the previous step) and log U taken in
+    // single precision: tau = lvl0 + log2(U) (ln 2 / kappa).  Errors: log2_32 <= kLog2Err32 + 2^-24 |log2 U| (the sum
+    // of exponent and mantissa logarithm is rounded once more), ln2_over_kappa and the fma one rounding each.
+    // Returns e_eval of these coefficients through `e_eval`.
+    __device__ __forceinline__ bool finish32_carried(double u_thr, float (&q)[kFloats], float lvl0, float e_lvl0, float &e_eval) const
+    {
+        e_eval = eval_error(q);
+        const float l2 = log2_32(u_thr);
+        const float lk = l2 * ln2_over_kappa;
+        const float tau = lvl0 + lk;
+        q[2 * NK] = tau;
+        const float e_tau = e_lvl0 + (kLog2Err32 + kUnit32 * fabsf(l2)) * ln2_over_kappa + 3.0f * kUnit32 * (fabsf(lk) + fabsf(tau));
+        float margin = 1.25f * (e_eval + e_tau + kUnit32 * (fabsf(tau) + 1.0f));
+        if (!(u_thr > 1e-290) || !(margin < 0.25f)) margin = INFINITY;
+        q[2 * NK + 1] = margin;
+        return lvl0 >= -1.0f && lvl0 <= 1.0f;  // (NaN fails)
     }
     // margin and threshold from the rounded coefficients q[0 .. 2 NK); false if the level of x is not finite
     __device__ __forceinline__ bool finish32(double u_thr, float (&q)[kFloats]) const
@@ -274,6 +302,7 @@ struct Curve32 {
         seg32 = s32;
         nseg = nseg_;
         kappa = kappa_;
+        ln2_over_kappa = (float)(0.6931471805599453 / kappa_);
         float m = 0.0f;
 #pragma unroll
         for (int g = 0; g + 1 < NK; ++g)

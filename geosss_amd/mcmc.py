@@ -118,7 +118,9 @@ class RejectionSphericalSliceSampler:
         self.max_tries = int(max_tries) if max_tries is not None else (1 << 20)
         self.chain_offset = int(chain_offset)
         self.variant = int(variant)
-        self.screen = bool(screen)  # fast mode: single-precision screening of the tries (same chains); False = all-double kernels
+        # fast mode: single-precision screening of the tries (same chains); False = the all-double kernels; "verify" = the
+        # default kernel with its screen's verdicts ignored where it can (GSSS_VARIANT_FAST_VERIFY: must give the same bits)
+        self.screen = screen if screen == "verify" else bool(screen)
         self._step = int(step_offset)
         self._target_dev = distribution._device_target(self.device)
         self._set_state(initial_state)
@@ -350,7 +352,8 @@ class RejectionSphericalSliceSampler:
         a.sampler = self._sampler
         a.mode = _MODES[self.mode]
         a.max_tries = min(self.max_tries, 2**31 - 1)
-        a.variant = self.variant if self.mode != "fast" else (0 if self.screen else _lib.VARIANT_FAST_DOUBLE)
+        a.variant = self.variant if self.mode != "fast" else (
+            _lib.VARIANT_FAST_VERIFY if self.screen == "verify" else (0 if self.screen else _lib.VARIANT_FAST_DOUBLE))
         if self._rng_state is not None:
             if replay is not None:
                 raise ValueError("replay and rng='numpy' are mutually exclusive")
