@@ -10,13 +10,13 @@ from . import _lib, diagnostics, registration, sphere
 from .diagnostics import IAT, acf, acf_fft, distance, n_eff
 from .distributions import (Bingham, BinghamFisher, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
                             brownian_curve, random_bingham)
-from .mcmc import (MetropolisHastings, RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, SphericalHMC,
-                   determine_burnin)
+from .mcmc import (IndependenceSampler, MetropolisHastings, MixtureRWMHIndependenceSampler, RejectionSphericalSliceSampler,
+                   ShrinkageSphericalSliceSampler, SphericalHMC, determine_burnin)
 from .registration import CoherentPointDrift, GaussianMixtureModel, PointCloud, RotationProjection
 from .sphere import sample_sphere, sample_sphere_device
 from .utils import SamplerLauncher, count_calls, counter
 
 __all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
-           "MetropolisHastings", "SphericalHMC", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
+           "MetropolisHastings", "SphericalHMC", "IndependenceSampler", "MixtureRWMHIndependenceSampler", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
            "sphere", "diagnostics", "registration", "CoherentPointDrift", "GaussianMixtureModel", "PointCloud", "RotationProjection", "IAT", "acf", "acf_fft", "distance", "n_eff"]

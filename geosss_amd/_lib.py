@@ -7,12 +7,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSSS_HIP_LIB") or os.path.join(_HERE, "libgsss_hip.so")  # env: side-by-side A/B builds
 
 VMF_MIXTURE, BINGHAM, CURVE_VMF, CPD = 1, 2, 3, 4
-SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
+SHRINK, REJECT, RWMH, HMC, INDEP, MIX = 0, 1, 2, 3, 4, 5
 MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 VARIANT_FAST_VERIFY = 101
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GsssError(RuntimeError):
@@ -37,7 +37,8 @@ class RunArgs(C.Structure):
                 ("rng_state_dev", C.c_void_p), ("samples_chain_rows", C.c_int64), ("placement", C.c_int32),
                 ("stats_lags", C.c_int32), ("stats_dev", C.c_void_p), ("stats_dirs_dev", C.c_void_p),
                 ("stats_modes", C.c_int32), ("n_leapfrog", C.c_int32), ("stepsize_dev", C.c_void_p),
-                ("n_accept_dev", C.c_void_p), ("momenta_dev", C.c_void_p), ("adapt_steps", C.c_int64)]
+                ("n_accept_dev", C.c_void_p), ("momenta_dev", C.c_void_p), ("adapt_steps", C.c_int64),
+                ("mixing_probability", C.c_double), ("adapt_left_dev", C.c_void_p), ("n_rwmh_dev", C.c_void_p)]
 
 
 # symbol -> (restype, argtypes); must list every function include/gsss.h declares

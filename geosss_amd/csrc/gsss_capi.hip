@@ -474,14 +474,19 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("need n_chains >= 0, n_steps >= 0, thin >= 1, max_tries >= 1");
         return GSSS_E_INVALID;
     }
-    const bool mh = a->sampler == GSSS_RWMH || a->sampler == GSSS_HMC;
+    const bool mh = a->sampler == GSSS_RWMH || a->sampler == GSSS_HMC || a->sampler == GSSS_INDEP || a->sampler == GSSS_MIX;
     if (a->sampler != GSSS_SHRINK && a->sampler != GSSS_REJECT && !mh) {
         set_error("unknown sampler %d", a->sampler);
         return GSSS_E_INVALID;
     }
     if (mh && (a->mode != GSSS_MODE_EXACT || !a->stepsize_dev || a->adapt_steps < 0 || a->stats_dev ||
                (a->sampler == GSSS_HMC && a->n_leapfrog < 1))) {
-        set_error("GSSS_RWMH / GSSS_HMC need GSSS_MODE_EXACT, stepsize_dev, adapt_steps >= 0, no stats_dev (HMC: n_leapfrog >= 1)");
+        set_error("GSSS_RWMH / GSSS_HMC / GSSS_INDEP / GSSS_MIX need GSSS_MODE_EXACT, stepsize_dev, adapt_steps >= 0, no stats_dev "
+                  "(HMC: n_leapfrog >= 1)");
+        return GSSS_E_INVALID;
+    }
+    if (a->sampler == GSSS_MIX && (!(a->mixing_probability >= 0.0 && a->mixing_probability <= 1.0) || !a->adapt_left_dev)) {
+        set_error("GSSS_MIX needs 0 <= mixing_probability <= 1 and adapt_left_dev");
         return GSSS_E_INVALID;
     }
     if (a->mode != GSSS_MODE_EXACT && a->mode != GSSS_MODE_FAST) {
@@ -586,7 +591,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         return fast_dispatch(t->tb, rb, replay, nullptr, st);
     }
     if (mh) {
-        if (a->rng_state_dev && a->sampler == GSSS_RWMH && t->tb.d < 3) {
+        if (a->rng_state_dev && (a->sampler == GSSS_RWMH || a->sampler == GSSS_MIX) && t->tb.d < 3) {
             set_error("numpy's gamma(1) is an exponential ziggurat, not restated: RWMH on numpy's stream needs d >= 3");
             return GSSS_E_UNSUPPORTED;
         }
@@ -596,6 +601,10 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         mb.momenta = a->sampler == GSSS_HMC ? a->momenta_dev : nullptr;
         mb.adapt_steps = a->adapt_steps;
         mb.n_leapfrog = a->n_leapfrog;
+        mb.kind = a->sampler;
+        mb.mix_alpha = a->mixing_probability;
+        mb.adapt_left = a->adapt_left_dev;
+        mb.n_rwmh = a->n_rwmh_dev;
         if (t->tb.kind == GSSS_CPD) return launch_cpd_mh(t->cpd_variant, draws, a->sampler, t->tb, rb, mb, st);
         switch (t->tb.kind) {
         case GSSS_VMF_MIXTURE: return launch_mh<VmfMixture>(vec, draws, a->sampler, t->tb, rb, mb, st);

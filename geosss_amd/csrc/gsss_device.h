@@ -379,6 +379,13 @@ struct PhiloxDraws {
         block(0u, u0, u1);
         return u0;
     }
+    // MixtureRWMHIndependenceSampler's choice of kernel (mcmc.py:213): the other half of block 0
+    __device__ __forceinline__ double mix_uniform() const
+    {
+        double u0, u1;
+        block(0u, u0, u1);
+        return u1;
+    }
 };
 
 template <class V>
@@ -432,6 +439,7 @@ struct ReplayDraws {
     __device__ __forceinline__ double next_try() { return take(); }
     __device__ __forceinline__ double chi(int) { return sqrt(2.0 * take()); }  // the recorded gamma(d/2) variate
     __device__ __forceinline__ double accept_uniform() { return take(); }
+    __device__ __forceinline__ double mix_uniform() { return take(); }
 };
 
 // numpy's own stream: PCG64 (XSL-RR 128/64) + Generator.random / uniform / standard_normal, so that
@@ -568,6 +576,7 @@ struct NumpyDraws {
     }
     __device__ __forceinline__ double chi(int) { return sqrt(2.0 * standard_gamma(0.5 * (double)d)); }  // mcmc.py:143
     __device__ __forceinline__ double accept_uniform() { return next_double(); }
+    __device__ __forceinline__ double mix_uniform() { return next_double(); }
 };
 
 // ------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 //   MetropolisHastings  (random-walk MH on the sphere)   geosss/mcmc.py:118-176
 //   SphericalHMC        (leapfrog on the sphere)          geosss/mcmc.py:236-332
 //   AdaptiveStepsize    (x 1.02 / x 0.98 during burn-in)  geosss/mcmc.py:80-115
+//   IndependenceSampler, MixtureRWMHIndependenceSampler    geosss/mcmc.py:179-234 (the RWMH kernel with another proposal)
 // One lane group per chain as in run_kernel (gsss_device.h); a transition has a fixed amount of work, so
 // the wavefront never diverges (numpy's gamma stream excepted).  log_prob / gradient are evaluated from the
 // point itself, operation by operation as the reference does (the targets' logp / grad functors).
@@ -16,6 +17,10 @@ struct MhBlock {
     double *momenta;      // [d][n_chains] or NULL: HMC, the momenta the reference keeps in the second half of its state
     int64_t adapt_steps;  // the first adapt_steps steps of this launch adapt the stepsize
     int32_t n_leapfrog;
+    int32_t kind;         // GSSS_RWMH kernels: GSSS_RWMH, GSSS_INDEP or GSSS_MIX (the proposal is chosen at run time)
+    double mix_alpha;     // GSSS_MIX: probability of the RWMH proposal
+    int64_t *adapt_left;  // GSSS_MIX: [n_chains] in/out, RWMH proposals that still adapt the stepsize
+    int64_t *n_rwmh;      // GSSS_MIX: [n_chains] or NULL, ADDED to
 };
 
 template <class V, template <class> class TT, template <class> class DR, int SAMPLER>
@@ -48,18 +53,23 @@ __global__ void __launch_bounds__(kBlock) mh_kernel(TargetBlock tb, RunBlock a, 
     dr.init(a, c, d);
     double eps = m.stepsize[c];
     int64_t n_acc = 0, until_keep = a.thin, row = 0;
+    int64_t adapt_left = (SAMPLER == GSSS_RWMH && m.kind == GSSS_MIX && m.adapt_left) ? m.adapt_left[c] : 0, n_rwmh = 0;
     int err = 0;
 
     for (int64_t s = 0; s < a.n_steps; ++s) {
         dr.begin_step(a.step_offset + (uint64_t)s);
         bool accepted;
         double y[V::N];
+        bool use_rwmh = true;
         if (SAMPLER == GSSS_RWMH) {
-            const double r = dr.chi(g);            // mcmc.py:143: r = sqrt(2 gamma(d / 2))
+            if (m.kind == GSSS_MIX) use_rwmh = dr.mix_uniform() < m.mix_alpha;  // mcmc.py:213
+            if (m.kind == GSSS_INDEP) use_rwmh = false;
+            double r = 0.0;
+            if (use_rwmh) r = dr.chi(g);           // mcmc.py:143: r = sqrt(2 gamma(d / 2))
             double z[V::N];
-            dr.normals(z, g);                      // mcmc.py:144
+            dr.normals(z, g);                      // mcmc.py:144 / :181 (the independence proposal is the projected normal vector)
 #pragma unroll
-            for (int i = 0; i < V::N; ++i) y[i] = r * x[i] + eps * z[i];
+            for (int i = 0; i < V::N; ++i) y[i] = use_rwmh ? r * x[i] + eps * z[i] : z[i];
             const double nrm = sqrt(vdot<V>(y, y)) + 1e-100;  // mcmc.py:145, sphere.py:10-18
 #pragma unroll
             for (int i = 0; i < V::N; ++i) y[i] = y[i] / nrm;
@@ -119,7 +129,17 @@ __global__ void __launch_bounds__(kBlock) mh_kernel(TargetBlock tb, RunBlock a, 
             for (int i = 0; i < V::N; ++i) x[i] = y[i];
         }
         n_acc += accepted ? 1 : 0;
-        if (s < m.adapt_steps) eps *= accepted ? 1.02 : 0.98;     // mcmc.py:113-115
+        if (SAMPLER == GSSS_RWMH && m.kind == GSSS_MIX) {         // mcmc.py:226-228: only RWMH proposals adapt, and only
+            if (use_rwmh) {                                       // they advance the burn-in counter (:113-115)
+                ++n_rwmh;
+                if (adapt_left > 0) {
+                    eps *= accepted ? 1.02 : 0.98;
+                    --adapt_left;
+                }
+            }
+        } else if (s < m.adapt_steps) {
+            eps *= accepted ? 1.02 : 0.98;                        // mcmc.py:113-115
+        }
         if (a.samples != nullptr && --until_keep == 0) {
             until_keep = a.thin;
             if (active) {
@@ -149,6 +169,10 @@ __global__ void __launch_bounds__(kBlock) mh_kernel(TargetBlock tb, RunBlock a, 
         if (g == 0) {
             m.stepsize[c] = eps;
             if (m.n_accept) m.n_accept[c] += n_acc;
+            if (SAMPLER == GSSS_RWMH && m.kind == GSSS_MIX) {
+                if (m.adapt_left) m.adapt_left[c] = adapt_left;
+                if (m.n_rwmh) m.n_rwmh[c] += n_rwmh;
+            }
             if (a.err && err) a.err[c] |= err;
         }
     }
@@ -191,7 +215,7 @@ int launch_mh(int vec_id, int draws, int sampler, const TargetBlock &tb, const R
 template <class V, template <class> class TT>
 int mh_dispatch(int draws, int sampler, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st)
 {
-    if (sampler == GSSS_RWMH) {
+    if (sampler == GSSS_RWMH || sampler == GSSS_INDEP || sampler == GSSS_MIX) {  // one kernel, the proposal chosen at run time (mb.kind)
         if (draws == kDrawsReplay) return do_mh<V, TT, ReplayDraws, GSSS_RWMH>(tb, rb, mb, st);
         if (draws == kDrawsNumpy) return do_mh<V, TT, NumpyDraws, GSSS_RWMH>(tb, rb, mb, st);
         return do_mh<V, TT, PhiloxDraws, GSSS_RWMH>(tb, rb, mb, st);

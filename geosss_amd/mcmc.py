@@ -566,6 +566,69 @@ class MetropolisHastings(RejectionSphericalSliceSampler):
         self._counter, self._burnin = int(d["counter"]), int(d["burnin"])
 
 
+class IndependenceSampler(MetropolisHastings):
+    """Metropolis-Hastings with the uniform distribution on the sphere as proposal (geosss/mcmc.py:179-182), many chains.
+    The class inherits RWMH's stepsize adaptation, which runs and changes nothing, exactly as in the reference."""
+
+    _sampler = _lib.INDEP
+
+
+class MixtureRWMHIndependenceSampler(MetropolisHastings):
+    """Mixture of the RWMH kernel (local moves, probability `mixing_probability`) and the independence kernel with uniform
+    proposal (global jumps), geosss/mcmc.py:185-234, many chains.  As in the reference only RWMH proposals adapt the
+    stepsize, and the burn-in counter only advances on them: a chain adapts during its first `burnin` RWMH proposals.
+    Attributes of the reference: `.alpha`, `.n_accept`, `.rwmh_counter`, `.indep_counter` (totals over chains; per chain:
+    `rwmh_counter_per_chain`); `.rwmh_stepsize_vals` (the stepsize after every RWMH proposal) is not recorded."""
+
+    _sampler = _lib.MIX
+
+    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, mixing_probability=0.5, **kwargs):
+        super().__init__(distribution, initial_state, seed, stepsize=stepsize, **kwargs)
+        self.alpha = float(mixing_probability)
+        if not 0.0 <= self.alpha <= 1.0:
+            raise ValueError("mixing_probability must lie in [0, 1]")
+        self._adapt_left = torch.zeros(self.n_chains, dtype=torch.int64, device=self._tdev)
+        self._n_rwmh = torch.zeros(self.n_chains, dtype=torch.int64, device=self._tdev)
+        self._steps_run = 0
+
+    def reset(self, burnin):
+        """AdaptiveStepsize.reset (mcmc.py:100-103); the counter it resets advances on RWMH proposals only (:226-228)."""
+        super().reset(burnin)
+        if hasattr(self, "_adapt_left"):
+            self._adapt_left.fill_(int(burnin))
+
+    def _launch_extra(self, a, n_steps):
+        super()._launch_extra(a, n_steps)
+        a.adapt_steps = 0
+        a.mixing_probability = self.alpha
+        a.adapt_left_dev = self._adapt_left.data_ptr()
+        a.n_rwmh_dev = self._n_rwmh.data_ptr()
+        self._steps_run += n_steps
+
+    @property
+    def rwmh_counter_per_chain(self):
+        return self._n_rwmh.cpu().numpy()
+
+    @property
+    def rwmh_counter(self):
+        return int(self._n_rwmh.sum().item())
+
+    @property
+    def indep_counter(self):
+        return self._steps_run * self.n_chains - self.rwmh_counter
+
+    def state_dict(self):
+        d = super().state_dict()
+        d.update(adapt_left=self._adapt_left.cpu().numpy(), n_rwmh=self.rwmh_counter_per_chain, steps_run=self._steps_run)
+        return d
+
+    def load_state_dict(self, d):
+        super().load_state_dict(d)
+        self._adapt_left.copy_(torch.from_numpy(np.asarray(d["adapt_left"], dtype=np.int64)))
+        self._n_rwmh.copy_(torch.from_numpy(np.asarray(d["n_rwmh"], dtype=np.int64)))
+        self._steps_run = int(d["steps_run"])
+
+
 class SphericalHMC(MetropolisHastings):
     """Spherical Hamiltonian Monte Carlo for many chains (geosss/mcmc.py:236-332): `n_steps` leapfrog steps of size
     `stepsize` along great circles, Metropolis correction with the Hamiltonian; needs the target's gradient (device

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 6
+#define GSSS_ABI_VERSION 7
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -45,6 +45,8 @@ extern "C" {
 #define GSSS_REJECT 1 /* RejectionSphericalSliceSampler.__next__  :357-374 */
 #define GSSS_RWMH 2   /* MetropolisHastings.__next__ (random-walk MH)  :138-167, AdaptiveStepsize :80-115 */
 #define GSSS_HMC 3    /* SphericalHMC.__next__ (leapfrog on the sphere) :270-319 */
+#define GSSS_INDEP 4  /* IndependenceSampler: proposal = a uniform point of the sphere          :179-182 */
+#define GSSS_MIX 5    /* MixtureRWMHIndependenceSampler: RWMH with probability alpha, else the independence proposal :185-234 */
 
 /* arithmetic of the proposal evaluation */
 #define GSSS_MODE_EXACT 0 /* y = cos*x + sin*u formed, log_prob(y) evaluated from y op by op as the reference does */
@@ -140,7 +142,7 @@ typedef struct gsss_run_args {
     uint64_t seed;
     uint64_t chain_offset;     /* global id of chain 0 of this call (< 2^48) */
     uint64_t step_offset;      /* global id of step 0 of this call  (< 2^48 - 1) */
-    int32_t sampler;           /* GSSS_SHRINK | GSSS_REJECT */
+    int32_t sampler;           /* GSSS_SHRINK | GSSS_REJECT | GSSS_RWMH | GSSS_HMC | GSSS_INDEP | GSSS_MIX */
     int32_t mode;              /* GSSS_MODE_EXACT | GSSS_MODE_FAST */
     int32_t max_tries;         /* > 0: give up a step after this many proposals */
     int32_t variant;           /* 0 = library's choice; otherwise a kernel variant id (gsss_variant_name) */
@@ -186,7 +188,17 @@ typedef struct gsss_run_args {
                                   0.98 after a rejected proposal (AdaptiveStepsize.adapt_stepsize during burn-in, mcmc.py:108-115).
                                   Draws per step, in the reference's order: RWMH gamma(d/2), d normals, one uniform; HMC d normals,
                                   one uniform (replay_dev holds the gamma variate itself; the Philox stream uses the norm of d
-                                  further normals, the same chi_d law; rng_state_dev restates numpy's gamma) */
+                                  further normals, the same chi_d law; rng_state_dev restates numpy's gamma).
+                                  GSSS_INDEP: d normals, one uniform (the stepsize is adapted like RWMH's, as the reference's class
+                                  inherits it, and never used).  GSSS_MIX: one uniform (RWMH iff it is < mixing_probability), then the
+                                  draws of the chosen proposal, then the accept uniform; on the Philox stream the two uniforms are the
+                                  two halves of block 0 (accept, mix) */
+    /* GSSS_MIX (MixtureRWMHIndependenceSampler, mcmc.py:185-234): */
+    double mixing_probability; /* alpha: probability of the RWMH kernel */
+    int64_t *adapt_left_dev;   /* [n_chains] in/out: RWMH proposals that still adapt the stepsize.  The reference's burn-in counter
+                                  only advances on RWMH proposals (mcmc.py:108-115 called from :226-228), so the adaptation of a chain
+                                  ends after `burnin` RWMH proposals, not after `burnin` steps; adapt_steps is unused */
+    int64_t *n_rwmh_dev;       /* [n_chains] or NULL; RWMH proposals are ADDED (rwmh_counter; indep_counter = steps - that) */
 } gsss_run_args;
 
 int gsss_abi_version(void);

@@ -26,6 +26,7 @@
  *   gor_gradient                geosss/distributions.py:88-89, 159-160, 223-227, 277-278
  *   gor_mh_run (RWMH)           geosss/mcmc.py:138-167 with AdaptiveStepsize :80-115
  *   gor_mh_run (spherical HMC)  geosss/mcmc.py:236-318
+ *   gor_mh_run (independence sampler, RWMH / independence mixture)  geosss/mcmc.py:179-234
  *
  * Parity pin: the reference's own tests hold no golden vectors for this path
  * (SURVEY.md §4); this oracle is pinned instead by the .npz files in tests/golden/, which
@@ -658,6 +659,8 @@ int gor_run(const gor_target *t, double *state, int64_t n_chains, int64_t n_step
 
 #define GOR_RWMH 2
 #define GOR_HMC 3
+#define GOR_INDEP 4 /* IndependenceSampler, mcmc.py:179-182 */
+#define GOR_MIX 5   /* MixtureRWMHIndependenceSampler, mcmc.py:185-234 */
 
 /* Distribution.gradient of the three target families.  BinghamFisher inherits Bingham.gradient in the
  * reference (distributions.py:106-114 defines log_prob only), i.e. 2 A x without b: restated as is. */
@@ -739,6 +742,16 @@ static double gor_draw_accept(gor_draws *g)
     return u[0];
 }
 
+/* the uniform that picks the kernel of MixtureRWMHIndependenceSampler (mcmc.py:213); Philox stream: the other half of block 0 */
+static double gor_draw_mix(gor_draws *g)
+{
+    if (g->pcg) return gor_npy_double(g->pcg);
+    if (g->replay) return gor_take(g);
+    double u[2];
+    gor_stream_block(g->seed, g->chain, g->step, 0u, u);
+    return u[1];
+}
+
 /* project(x, v) of mcmc.py:231-235 : x - v (v . x) */
 static void gor_project(double *x, const double *v, int d)
 {
@@ -754,12 +767,16 @@ static void gor_project(double *x, const double *v, int d)
  *            first `adapt_steps` steps of this call
  *   n_accept [n_chains] ADDED to;  accept_trace / stepsize_trace [n_chains][n_steps] or NULL
  * Draws per step in the reference's order: RWMH gamma(d/2), d normals, 1 uniform; HMC d normals, 1 uniform.
+ * GOR_INDEP (mcmc.py:179-182): d normals, 1 uniform; the inherited stepsize adaptation runs and is never used.
+ * GOR_MIX (mcmc.py:185-234): 1 uniform (RWMH iff < mix_alpha), the chosen proposal's draws, 1 uniform; only RWMH proposals
+ * adapt the stepsize and advance the burn-in counter: adapt_left [n_chains] in/out counts the RWMH proposals that still
+ * adapt (adapt_steps unused); n_rwmh [n_chains] or NULL is ADDED to; proposal_trace [n_chains][n_steps] or NULL gets 1 for RWMH.
  */
 int gor_mh_run(const gor_target *t, double *state, double *momenta, int64_t n_chains, int64_t n_steps, int64_t thin,
                uint64_t seed, uint64_t chain_offset, uint64_t step_offset, int sampler, double *stepsize,
                int64_t adapt_steps, int n_leapfrog, double *samples, int64_t *n_accept, int32_t *err,
                const double *replay, int64_t replay_stride, int n_threads, uint64_t *pcg_state, uint8_t *accept_trace,
-               double *stepsize_trace)
+               double *stepsize_trace, double mix_alpha, int64_t *adapt_left, int64_t *n_rwmh, uint8_t *proposal_trace)
 {
     int d = t->d;
     if (thin < 1) thin = 1;
@@ -793,12 +810,18 @@ int gor_mh_run(const gor_target *t, double *state, double *momenta, int64_t n_ch
             memset(v, 0, sizeof(double) * (size_t)d);
         for (int64_t s = 0; s < n_steps; ++s) {
             g.step = step_offset + (uint64_t)s;
-            int accepted;
-            if (sampler == GOR_RWMH) {
-                double r = gor_draw_chi(&g);                       /* mcmc.py:143 */
-                gor_draw_normals(&g, z);                           /* mcmc.py:144 */
-                for (int i = 0; i < d; ++i) y[i] = r * x[i] + eps * z[i];
-                gor_radial_projection(y, d, y);                    /* mcmc.py:145 */
+            int accepted, use_rwmh = 1;
+            if (sampler == GOR_RWMH || sampler == GOR_INDEP || sampler == GOR_MIX) {
+                if (sampler == GOR_MIX) use_rwmh = gor_draw_mix(&g) < mix_alpha; /* mcmc.py:213 */
+                if (sampler == GOR_INDEP) use_rwmh = 0;
+                if (use_rwmh) {
+                    double r = gor_draw_chi(&g);                   /* mcmc.py:143 */
+                    gor_draw_normals(&g, z);                       /* mcmc.py:144 */
+                    for (int i = 0; i < d; ++i) y[i] = r * x[i] + eps * z[i];
+                } else {
+                    gor_draw_normals(&g, y);                       /* mcmc.py:181 */
+                }
+                gor_radial_projection(y, d, y);                    /* mcmc.py:145, :182 */
                 double prob = gor_logprob(t, y) - gor_logprob(t, x); /* mcmc.py:152 */
                 accepted = log(gor_draw_accept(&g)) < prob;        /* mcmc.py:153 */
                 if (accepted) memcpy(x, y, sizeof(double) * (size_t)d);
@@ -834,7 +857,18 @@ int gor_mh_run(const gor_target *t, double *state, double *momenta, int64_t n_ch
                 }
             }
             if (n_accept) n_accept[c] += accepted;
-            if (s < adapt_steps) eps *= accepted ? 1.02 : 0.98;    /* mcmc.py:113-115 */
+            if (sampler == GOR_MIX) {                              /* mcmc.py:226-228 */
+                if (use_rwmh) {
+                    if (n_rwmh) n_rwmh[c] += 1;
+                    if (adapt_left && adapt_left[c] > 0) {         /* mcmc.py:113-115: the counter advances on RWMH proposals */
+                        eps *= accepted ? 1.02 : 0.98;
+                        adapt_left[c] -= 1;
+                    }
+                }
+                if (proposal_trace) proposal_trace[c * n_steps + s] = (uint8_t)use_rwmh;
+            } else if (s < adapt_steps) {
+                eps *= accepted ? 1.02 : 0.98;                     /* mcmc.py:113-115 */
+            }
             if (accept_trace) accept_trace[c * n_steps + s] = (uint8_t)accepted;
             if (stepsize_trace) stepsize_trace[c * n_steps + s] = eps;
             if (samples && (s + 1) % thin == 0)

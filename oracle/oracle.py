@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "libgsss_oracle.so")
 
 VMF_MIXTURE, BINGHAM, CURVE_VMF, CPD = 1, 2, 3, 4
-SHRINK, REJECT, RWMH, HMC = 0, 1, 2, 3
+SHRINK, REJECT, RWMH, HMC, INDEP, MIX = 0, 1, 2, 3, 4, 5
 ERR_MAX_TRIES, ERR_NONFINITE, ERR_REPLAY_EXHAUSTED = 1, 2, 4
 
 
@@ -206,7 +206,7 @@ def npy_gamma(pcg_words, shape, n):
 
 def mh_run(target, state, n_steps, sampler=RWMH, stepsize=0.1, adapt_steps=0, n_leapfrog=10, seed=0, chain_offset=0,
            step_offset=0, thin=1, keep_samples=True, replay=None, n_threads=1, numpy_seed=None, momenta=None,
-           trace=False):
+           trace=False, mixing_probability=0.5, adapt_left=None):
     """MetropolisHastings / SphericalHMC (geosss/mcmc.py:118-332) for every row of `state`.
     Returns dict(state, momenta, samples, n_accept, stepsize, err, accept (trace), stepsize_trace, pcg)."""
     state = np.array(state, dtype=np.float64, order="C", copy=True)
@@ -234,12 +234,17 @@ def mh_run(target, state, n_steps, sampler=RWMH, stepsize=0.1, adapt_steps=0, n_
         assert len(pcg) == n
     acc = np.zeros((n, n_steps), dtype=np.uint8) if trace else None
     eps_tr = np.zeros((n, n_steps)) if trace else None
+    prop = np.zeros((n, n_steps), dtype=np.uint8) if trace else None
+    left = np.broadcast_to(np.asarray(adapt_steps if adapt_left is None else adapt_left, dtype=np.int64), (n,)).copy()
+    n_rwmh = np.zeros(n, dtype=np.int64)
     lib().gor_mh_run(C.byref(target.c), _p(state), _p(mom), C.c_int64(n), C.c_int64(n_steps), C.c_int64(thin),
                      C.c_uint64(seed), C.c_uint64(chain_offset), C.c_uint64(step_offset), C.c_int(sampler), _p(eps),
                      C.c_int64(adapt_steps), C.c_int(n_leapfrog), _p(samples), _p(n_accept), _p(err), _p(replay),
-                     C.c_int64(stride), C.c_int(n_threads), _p(pcg), _p(acc), _p(eps_tr))
+                     C.c_int64(stride), C.c_int(n_threads), _p(pcg), _p(acc), _p(eps_tr), C.c_double(mixing_probability),
+                     _p(left), _p(n_rwmh), _p(prop))
     return dict(state=state[0] if single else state, momenta=mom[0] if single else mom, samples=samples,
-                n_accept=n_accept, stepsize=eps, err=err, accept=acc, stepsize_trace=eps_tr, pcg=pcg)
+                n_accept=n_accept, stepsize=eps, err=err, accept=acc, stepsize_trace=eps_tr, pcg=pcg,
+                adapt_left=left, n_rwmh=n_rwmh, use_rwmh=prop)
 
 
 def sample_sphere(seed, n, d, chain_offset=0):

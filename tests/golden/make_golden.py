@@ -399,7 +399,7 @@ def make_diagnostics():
     save("diagnostics_kat.npz", **arrays)
 
 
-def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10):
+def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10, alpha=0.5):
     """One chain of the reference's MetropolisHastings (mcmc.py:118-176) or SphericalHMC (:236-332) with every draw
     recorded in consumption order (RWMH: gamma(d/2), d normals, 1 uniform; HMC: d normals, 1 uniform), the state,
     the accept flag and the adapted stepsize after every step (AdaptiveStepsize adapts during the first `burnin`
@@ -407,6 +407,10 @@ def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10):
     def build():
         if kind == "rwmh":
             return gs.MetropolisHastings(pdf, np.array(x0, dtype=float), seed, stepsize=stepsize)
+        if kind == "indep":   # mcmc.py:179-182: d normals, 1 uniform per step
+            return gs.mcmc.IndependenceSampler(pdf, np.array(x0, dtype=float), seed, stepsize=stepsize)
+        if kind == "mix":     # mcmc.py:185-234: 1 uniform, then the chosen kernel's draws, 1 uniform
+            return gs.mcmc.MixtureRWMHIndependenceSampler(pdf, np.array(x0, dtype=float), seed, stepsize=stepsize, mixing_probability=alpha)
         return gs.SphericalHMC(pdf, np.array(x0, dtype=float), seed, stepsize=stepsize, n_steps=n_leapfrog)
     d = len(x0)
     s0 = build()
@@ -431,6 +435,12 @@ def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10):
                stepsize0=np.float64(stepsize), n_leapfrog=np.int64(n_leapfrog), sampler=np.array(kind))
     if kind == "hmc":
         out["momenta"] = np.array(s.state[d:])
+    if kind == "mix":
+        per_step = np.diff(np.array(offs))
+        out.update(use_rwmh=(per_step == d + 3).astype(np.int8), rwmh_counter=np.int64(s.rwmh_counter),
+                   indep_counter=np.int64(s.indep_counter), rwmh_stepsize_vals=np.array(s.rwmh_stepsize_vals),
+                   alpha=np.float64(alpha))
+        assert int(out["use_rwmh"].sum()) == s.rwmh_counter
     return out
 
 
@@ -449,6 +459,19 @@ def make_mh():
             X = rsphere.radial_projection(rng.standard_normal((64, d)))
             grad = np.array([pdf.gradient(x) for x in X])
             save(f"mh_{kind}_{name}.npz", x0=np.array(x0), grad_X=X, grad=grad, **flat_params(target_params(pdf)), **rec)
+
+
+def make_mh_kernels():
+    """IndependenceSampler / MixtureRWMHIndependenceSampler reference chains (mcmc.py:179-234)."""
+    plan = [("vmfmix_readme", 600, 200, 0.1, 0.5), ("bingham_d10_vmax30", 500, 150, 0.1, 0.7), ("curve_d10_kappa800", 400, 150, 0.1, 0.5),
+            ("bingham_d5_dense", 300, 100, 0.1, 0.3)]
+    for name, n, burn, eps, alpha in plan:
+        pdf, x0, seed, _ = cases()[name]
+        for kind in ("indep", "mix"):
+            rec = record_mh(kind, pdf, x0, seed + 2000, n, burn, eps, alpha=alpha)
+            extra = f", {int(rec['rwmh_counter'])} RWMH proposals" if kind == "mix" else ""
+            print(f"{kind}_{name}: {n} steps, accept rate {rec['n_accept'] / n:.3f}, final stepsize {rec['stepsize_trace'][-1]:.4f}{extra}")
+            save(f"mh_{kind}_{name}.npz", x0=np.array(x0), **flat_params(target_params(pdf)), **rec)
 
 
 def cpd_cases():
@@ -495,7 +518,9 @@ def make_cpd():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh", "cpd"]
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh", "mhk", "cpd"]
+    if "mhk" in what:
+        make_mh_kernels()
     if "cpd" in what:
         make_cpd()
     if "mh" in what:

@@ -1,5 +1,6 @@
-"""GPU parity of the paper's baselines -- MetropolisHastings (geosss/mcmc.py:118-176) and SphericalHMC (:236-332) --
-through the C ABI (GSSS_RWMH / GSSS_HMC) against the reference's recorded chains and the CPU oracle."""
+"""GPU parity of the paper's baselines -- MetropolisHastings (geosss/mcmc.py:118-176), SphericalHMC (:236-332),
+IndependenceSampler (:179-182) and MixtureRWMHIndependenceSampler (:185-234) -- through the C ABI (GSSS_RWMH / GSSS_HMC /
+GSSS_INDEP / GSSS_MIX) against the reference's recorded chains and the CPU oracle."""
 import os
 
 import numpy as np
@@ -26,6 +27,11 @@ def build(gs, z, x0, seed, **kw):
     pdf = product_target(z)
     if str(z["sampler"]) == "rwmh":
         return gs.MetropolisHastings(pdf, x0, seed, stepsize=float(z["stepsize0"]), **kw)
+    if str(z["sampler"]) == "indep":
+        return gs.IndependenceSampler(pdf, x0, seed, stepsize=float(z["stepsize0"]), **kw)
+    if str(z["sampler"]) == "mix":
+        return gs.MixtureRWMHIndependenceSampler(pdf, x0, seed, stepsize=float(z["stepsize0"]),
+                                                 mixing_probability=float(z["alpha"]), **kw)
     return gs.SphericalHMC(pdf, x0, seed, stepsize=float(z["stepsize0"]), n_steps=int(z["n_leapfrog"]), **kw)
 
 
@@ -63,6 +69,8 @@ def test_replay_reproduces_reference_chain(gs, name, variant):
     if h == n:
         assert s.n_accept == int(z["n_accept"])
         assert abs(s.stepsize / z["stepsize_trace"][-1] - 1) < 1e-12
+    if str(z["sampler"]) == "mix":
+        assert s.rwmh_counter == int(z["rwmh_counter"]) and s.indep_counter == int(z["indep_counter"])
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -83,7 +91,9 @@ def test_reference_chain_from_seed(gs, name):
 
 @pytest.mark.parametrize("name", ["mh_rwmh_vmfmix_readme", "mh_hmc_vmfmix_readme", "mh_rwmh_bingham_d10_vmax30",
                                   "mh_hmc_bingham_d10_vmax30", "mh_rwmh_curve_d10_kappa800", "mh_hmc_curve_d10_kappa800",
-                                  "mh_rwmh_curve_d50_kappa800", "mh_hmc_curve_d50_kappa800", "mh_hmc_bingham_d5_dense"])
+                                  "mh_rwmh_curve_d50_kappa800", "mh_hmc_curve_d50_kappa800", "mh_hmc_bingham_d5_dense",
+                                  "mh_indep_vmfmix_readme", "mh_mix_vmfmix_readme", "mh_mix_bingham_d10_vmax30",
+                                  "mh_indep_bingham_d5_dense", "mh_mix_curve_d10_kappa800"])
 def test_philox_stream_matches_oracle(gs, oracle, name):
     """Many chains on the library's counter-based stream: device = oracle (accept counts exactly, adapted stepsizes and
     states to rounding), for any split of the steps over launches."""
@@ -91,16 +101,20 @@ def test_philox_stream_matches_oracle(gs, oracle, name):
     tgt = oracle.Target.from_fixture(z)
     d = len(z["x0"])
     hmc = str(z["sampler"]) == "hmc"
+    kind = {"rwmh": oracle.RWMH, "hmc": oracle.HMC, "indep": oracle.INDEP, "mix": oracle.MIX}[str(z["sampler"])]
     n_chains, n_steps, burn = (300, 30, 12) if d <= 10 else (64, 16, 6)
     x0 = oracle.sample_sphere(4, n_chains, d, chain_offset=50)
-    want = oracle.mh_run(tgt, x0, n_steps, sampler=oracle.HMC if hmc else oracle.RWMH, stepsize=float(z["stepsize0"]),
-                         adapt_steps=burn, n_leapfrog=10, seed=31, chain_offset=50, step_offset=3, n_threads=8)
+    want = oracle.mh_run(tgt, x0, n_steps, sampler=kind, stepsize=float(z["stepsize0"]),
+                         adapt_steps=burn, n_leapfrog=10, seed=31, chain_offset=50, step_offset=3, n_threads=8,
+                         mixing_probability=float(z["alpha"]) if kind == oracle.MIX else 0.5)
     s = build(gs, z, x0, 31, chain_offset=50, step_offset=3)
     s.reset(burn)
     s.advance(7)
     s.advance(n_steps - 7)
     # chains whose trajectories passed within rounding of an accept threshold may legitimately differ: none here
     assert np.array_equal(s.n_accept_per_chain, want["n_accept"])
+    if kind == oracle.MIX:
+        assert np.array_equal(s.rwmh_counter_per_chain, want["n_rwmh"]) and 0 < s.rwmh_counter < n_chains * n_steps
     assert np.max(np.abs(s.stepsize / want["stepsize"] - 1)) < 1e-12
     assert np.max(np.abs(s.state[:, :d] - want["state"])) < (1e-8 if hmc else 1e-10)
 
@@ -132,6 +146,36 @@ def test_sample_api_and_launcher(gs):
         L.run("kent")
     with pytest.raises(ValueError):
         gs.MetropolisHastings(pdf, z["x0"], 1, mode="fast")
+
+
+def test_independence_and_mixture_kernels_api(gs):
+    """IndependenceSampler / MixtureRWMHIndependenceSampler as the reference's classes are called (mcmc.py:179-234,
+    scripts/mixture_vMF_rwmh_indep.py): ctor keywords, sample(n, burnin), counters; on the two-mode README-like mixture the
+    mixture kernel visits both hemispheres while plain RWMH with a small step stays where it started."""
+    mus = 80.0 * np.array([[0.0, 0.0, 1.0], [0.0, 0.0, -1.0]])
+    pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mus])
+    x0 = np.tile([0.0, 0.0, 1.0], (4000, 1))
+    mix = gs.MixtureRWMHIndependenceSampler(pdf, x0, 11, stepsize=0.1, mixing_probability=0.8)
+    X = mix.sample(300, burnin=100)
+    assert X.shape == (4000, 300, 3) and mix.alpha == 0.8
+    assert mix.rwmh_counter + mix.indep_counter == 399 * 4000
+    assert abs(mix.rwmh_counter / (399 * 4000) - 0.8) < 0.01
+    frac_south = float(np.mean(mix.state[:, 2] < 0))
+    assert 0.35 < frac_south < 0.65, frac_south
+    rw = gs.MetropolisHastings(pdf, x0, 11, stepsize=0.1)
+    rw.sample(300, burnin=100)
+    assert float(np.mean(rw.state[:, 2] < 0)) < 0.01
+    ind = gs.IndependenceSampler(pdf, x0[0], 3)
+    Y = ind.sample(500, burnin=0.2)
+    assert Y.shape == (500, 3) and 0 < ind.n_accept < 599 and np.max(np.abs(np.linalg.norm(Y, axis=1) - 1)) < 1e-12
+    sd = mix.state_dict()
+    again = gs.MixtureRWMHIndependenceSampler(pdf, x0, 11, stepsize=0.1, mixing_probability=0.8)
+    again.load_state_dict(sd)
+    mix.advance(20)
+    again.advance(20)
+    assert np.array_equal(mix.state, again.state) and again.rwmh_counter == mix.rwmh_counter
+    with pytest.raises(ValueError):
+        gs.MixtureRWMHIndependenceSampler(pdf, x0, 1, mixing_probability=1.5)
 
 
 def test_baselines_sample_the_target(gs):

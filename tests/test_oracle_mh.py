@@ -1,6 +1,7 @@
-"""The oracle's restatement of MetropolisHastings (geosss/mcmc.py:118-176) and SphericalHMC (:236-332) against chains
-the reference itself produced (tests/golden/mh_*.npz, written by make_golden.py mh): replaying the recorded draws and
--- numpy's gamma / normal / uniform stream restated -- from the seed alone."""
+"""The oracle's restatement of MetropolisHastings (geosss/mcmc.py:118-176), SphericalHMC (:236-332), IndependenceSampler
+(:179-182) and MixtureRWMHIndependenceSampler (:185-234) against chains the reference itself produced
+(tests/golden/mh_*.npz, written by make_golden.py mh / mhk): replaying the recorded draws and -- numpy's gamma / normal /
+uniform stream restated -- from the seed alone."""
 import os
 
 import numpy as np
@@ -32,8 +33,10 @@ def horizon(z):
 
 def _run(oracle, z, **kw):
     tgt = oracle.Target.from_fixture(z)
-    kind = oracle.RWMH if str(z["sampler"]) == "rwmh" else oracle.HMC
+    kind = {"rwmh": oracle.RWMH, "hmc": oracle.HMC, "indep": oracle.INDEP, "mix": oracle.MIX}[str(z["sampler"])]
     n = len(z["states"]) - 1
+    if kind == oracle.MIX:
+        kw["mixing_probability"] = float(z["alpha"])
     return oracle.mh_run(tgt, z["x0"], n, sampler=kind, stepsize=float(z["stepsize0"]), adapt_steps=int(z["burnin"]),
                          n_leapfrog=int(z["n_leapfrog"]), trace=True, **kw)
 
@@ -41,6 +44,8 @@ def _run(oracle, z, **kw):
 @pytest.mark.parametrize("name", CASES)
 def test_gradient_kat(oracle, name):
     z = golden(name + ".npz")
+    if "grad_X" not in z.files:
+        pytest.skip("the gradient known answers live in the RWMH / HMC fixtures of the same target")
     if len(z["grad_X"]) == 0:
         pytest.skip("registration targets: log_prob only (RWMH); their gradient is not restated")
     tgt = oracle.Target.from_fixture(z)
@@ -60,6 +65,11 @@ def test_replay_reproduces_reference_chain(oracle, name):
     assert np.max(np.abs(out["stepsize_trace"][0] / z["stepsize_trace"] - 1)) < 1e-13
     if "momenta" in z.files and h == len(z["states"]) - 1:
         assert np.max(np.abs(out["momenta"] - z["momenta"])) < 1e-8
+    if str(z["sampler"]) == "mix":     # which kernel proposed, the counters, the stepsize after every RWMH proposal
+        assert np.array_equal(out["use_rwmh"][0], z["use_rwmh"])
+        assert int(out["n_rwmh"][0]) == int(z["rwmh_counter"]) and len(z["states"]) - 1 - int(out["n_rwmh"][0]) == int(z["indep_counter"])
+        assert np.max(np.abs(out["stepsize_trace"][0][z["use_rwmh"].astype(bool)] / z["rwmh_stepsize_vals"] - 1)) < 1e-13
+        assert int(out["adapt_left"][0]) == max(0, int(z["burnin"]) - int(z["rwmh_counter"]))
 
 
 @pytest.mark.parametrize("name", CASES)
