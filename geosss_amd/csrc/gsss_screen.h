@@ -233,12 +233,21 @@ struct Curve32 {
             const float A = ay * st;
             const float B = fmaf(-ay, ct, by);
             const float h2 = fmaf(A, A, B * B);
-            const float rh = h2 > 0.0f ? __builtin_amdgcn_rsqf(h2) : 0.0f;
-            const bool at_a = B < 0.0f || (B == 0.0f && A >= 0.0f);
+            // (straight-line: all three candidates are formed and selected -- left to short-circuit operators and nested
+            // conditionals the compiler builds three levels of exec-mask branches per segment)
+            const float rs = __builtin_amdgcn_rsqf(h2);
+            const float rh = h2 > 0.0f ? rs : 0.0f;
+            const bool at_a = (B < 0.0f) | ((B == 0.0f) & (A >= 0.0f));
             const bool at_b = A * rh < ct;
-            const float num = at_a ? st * ay : (at_b ? st * by : h2 * rh);
-            if (g < nseg) best = fmaxf(best, fminf(fmaxf(num * rden, -1.0f), 1.0f));
+            const float n_a = st * ay, n_b = st * by, n_i = h2 * rh;
+            float num = at_b ? n_b : n_i;
+            num = at_a ? n_a : num;
+            const float xc = fminf(fmaxf(num * rden, -1.0f), 1.0f);
+            best = fmaxf(best, g < nseg ? xc : -INFINITY);
             ay = by;
+            // two segments at a time (they pair up in v_pk_* instructions); all NK - 1 side by side cost 8 more registers
+            // where the callers have none to spare (measured, d = 10 / 50: 30.8 / 64.2 -> 29.8 / 60.9 ms)
+            if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
         return best;
     }
@@ -590,18 +599,13 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
                     float s32, c32;
                     sincos_rev32(theta, s32, c32);
                     const int verdict = tp.screen(reinterpret_cast<const float (&)[TP::kCoef32Floats]>(cur.q), c32, s32);
-                    if (verdict < 0) {
-                        if (shrink) {  // mcmc.py:400
-                            if (theta < 0.0)
-                                cur.lo = theta;
-                            else
-                                cur.hi = theta;
-                        }
-                    } else {
-                        cur.aux = theta;
-                        cur.status = verdict > 0 ? kFinalAccept : kFinalDecide;
-                        stopped = true;
-                    }
+                    // (selects, not branches: four exec-mask regions per try otherwise)
+                    const bool rej = verdict < 0, neg = theta < 0.0;
+                    cur.lo = (rej & shrink & neg) ? theta : cur.lo;   // mcmc.py:400
+                    cur.hi = (rej & shrink & !neg) ? theta : cur.hi;
+                    cur.aux = rej ? cur.aux : theta;
+                    cur.status = rej ? cur.status : (verdict > 0 ? kFinalAccept : kFinalDecide);
+                    stopped = !rej;
                 }
             }
         }
