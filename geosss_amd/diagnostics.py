@@ -104,6 +104,40 @@ def mode_kl(occupancy, weights):
     return _back((p * torch.log(p / w)).sum(), occupancy)
 
 
+def saff_sphere(n=1000):
+    """n points spread over S^2 along the Saff-Kuijlaars spiral, as the reference's evaluation notebooks lay out their
+    histogram cells (scripts/visualize_curve_vMF.ipynb `saff_sphere`): heights h_k equally spaced in [-1, 1], azimuth
+    advancing by 3.6 / sqrt(n (1 - h_k^2)); the two poles at azimuth 0."""
+    h = np.linspace(-1.0, 1.0, n)
+    phi = np.zeros(n)
+    phi[1:-1] = np.cumsum(3.6 / np.sqrt(n * (1.0 - h[1:-1] ** 2)))   # azimuth of point k: the increments of points 1 .. k
+    theta = np.arccos(h)
+    return np.stack([np.cos(phi) * np.sin(theta), np.sin(phi) * np.sin(theta), np.cos(theta)], axis=1)
+
+
+def grid_kl(pdf, samples, n_saff=1500, eps=1e-12):
+    """KL divergence between a target on S^2 and the draws, the estimator of the reference's curve evaluation
+    (scripts/visualize_curve_vMF.ipynb `calc_kld`): p = the target's probabilities on the `n_saff` spiral points
+    (normalised over them), q = the share of draws whose nearest spiral point is each cell (+ eps), summed over the
+    cells with p > eps.  samples: (draws, 3) or (chains, draws, 3) -> one value per chain.  Runs where the draws live."""
+    s = _t(samples).to(torch.float64)
+    single = s.dim() == 2
+    if single:
+        s = s[None]
+    grid_np = saff_sphere(n_saff)
+    logp = torch.as_tensor(np.asarray(pdf.log_prob(grid_np), dtype=np.float64), device=s.device)
+    p = torch.exp(logp - torch.logsumexp(logp, 0))
+    grid = torch.as_tensor(grid_np, device=s.device)
+    out = []
+    for chain in s:                                    # nearest spiral point = largest dot product on the unit sphere
+        cell = torch.cat([torch.argmax(c @ grid.T, dim=1) for c in chain.split(1 << 18)])
+        q = torch.bincount(cell, minlength=n_saff).to(torch.float64) / len(cell) + eps
+        m = p > eps
+        out.append((p[m] * (torch.log(p[m]) - torch.log(q[m]))).sum())
+    kl = torch.stack(out)
+    return _back(kl[0] if single else kl, samples)
+
+
 def iat_from_acf(ac):
     """The IAT heuristic of utils.py:119-131 applied to a given autocorrelation (lags 0 .. m-1 along the last
     axis): adjacent-pair sums from lag 2, truncated at the first negative pair."""

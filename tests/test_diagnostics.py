@@ -99,3 +99,32 @@ def test_running_statistics_host_math_against_reference_kat():
     Xb, mode = z["bingham_X"], z["bingham_mode"]
     rb = dg.from_running(torch.as_tensor(accumulate_numpy(Xb, np.eye(10)[0], mode, np.zeros((0, 10)), 8)[:, None]), 10, 0, 8)
     assert abs(float(rb["hopping_frequency"][0]) - float(z["bingham_hop"])) < 1e-15
+
+
+def test_spiral_grid_and_grid_kl():
+    """diagnostics.saff_sphere lays out the cells of the reference's KL estimate (scripts/visualize_curve_vMF.ipynb
+    `saff_sphere`, `calc_kld`): unit vectors from pole to pole, heights equally spaced, azimuth advancing by
+    3.6 / sqrt(n (1 - h^2)); grid_kl of draws laid exactly on the grid in proportion to p is ~0, of uniform draws the
+    KL between p and the uniform histogram."""
+    from geosss_amd import diagnostics as D
+    g = D.saff_sphere(1500)
+    assert g.shape == (1500, 3) and np.max(np.abs(np.linalg.norm(g, axis=1) - 1)) < 1e-15
+    assert np.allclose(g[0], [0, 0, -1], atol=1e-7) and np.allclose(g[-1], [0, 0, 1], atol=1e-7)
+    assert np.allclose(np.diff(g[:, 2]), 2 / 1499)
+    az = np.unwrap(np.arctan2(g[1:-1, 1], g[1:-1, 0]))
+    assert np.allclose(np.diff(az), 3.6 / np.sqrt(1500 * (1 - g[2:-1, 2] ** 2)), atol=1e-9)
+
+    class Pdf:                                         # a smooth density on S^2
+        def log_prob(self, x):
+            return 3.0 * np.asarray(x)[:, 2]
+    p = np.exp(3.0 * g[:, 2]); p /= p.sum()
+    counts = np.rint(p * 500_000).astype(int)
+    on_grid = np.repeat(g, counts, axis=0)
+    assert abs(float(D.grid_kl(Pdf(), torch.from_numpy(on_grid), 1500))) < 1e-3
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal((100_000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    cell = np.argmax(u @ g.T, axis=1)
+    q = np.bincount(cell, minlength=1500) / len(u) + 1e-12
+    want = float(np.sum(p * (np.log(p) - np.log(q))))
+    got = D.grid_kl(Pdf(), np.stack([u, u]), 1500)
+    assert got.shape == (2,) and abs(got[0] - want) < 1e-9
