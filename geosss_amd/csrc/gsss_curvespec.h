@@ -30,10 +30,12 @@
 
 namespace gsss {
 
-// wavefronts per SIMD asked of the compiler (Q <= 2 / larger).  Measured on MI355X, d = 10 / 50 / 200, ms per 10^8 chain-steps:
-// 2: 43.7 / 81.1 / 154;  3: 34.7 / 66.1 / 245;  4 (28 registers spilled): 31.7 / 63.0
+// Wavefronts per SIMD asked of the compiler (d <= 64 with <= 10 knots / larger shapes): the most the kernels reach WITHOUT spilling registers.
+// Measured on MI355X (ms per 10^8 chain-steps at d = 10 / 50): 2 wavefronts 43.7 / 81.1, 3 wavefronts 34.7 / 66.1, 4 wavefronts
+// with 28-38 registers spilled 29.7 / 60.8 -- but then the spill traffic reaches HBM (294 MB of scratch for 25 000 wavefronts
+// do not fit the L2): 3.9 GB / 33 GB per launch against 0.17 / 0.48 GB of algorithmic bytes.  Three it is.
 #ifndef GSSS_CS_WAVES
-#define GSSS_CS_WAVES 4
+#define GSSS_CS_WAVES 3
 #endif
 #ifndef GSSS_CS_WAVES_BIG
 #define GSSS_CS_WAVES_BIG 2
@@ -48,7 +50,8 @@ template <int L, int Q, int NK>
 __host__ __device__ constexpr size_t curvespec_lds_doubles()
 {
     return (size_t)NK * (4 * Q * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
-           (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2;
+           (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2 +
+           (Q >= 2 ? (size_t)4 * Q * kBlock : 0);  // Q >= 2: the tangent u rests in LDS while the tries run
 }
 
 // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397),
@@ -78,7 +81,7 @@ __device__ __forceinline__ bool curvespec_decide(const FastCurve<1, NK> &scl, co
 }
 
 template <int L, int Q, int NK, bool REPLAY>
-__global__ void __launch_bounds__(kBlock, Q <= 2 ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
     using V = CoopVec<L, 4 * Q>;
     using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level
@@ -108,6 +111,10 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? GSSS_CS_WAVES : GSSS_CS_WAVES
     double *ring = scr + 2;
     double *coef = ring + kRing;  // [2 NK]: a_i.x | a_i.u of the step (for the double-precision decisions)
     const fm::Tables tab = stage_tables(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L));
+    // Q >= 2 (d > 64): u is only needed again when the chain moves; its 8 Q registers are lent to the try loop meanwhile
+    // (slot i of thread t at [i][t]: conflict-free)
+    constexpr bool kParkU = Q >= 2;
+    double *upark = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2 + threadIdx.x;
     Scalar sc;
     sc.knots = lds;
     sc.seg = sg;
@@ -216,7 +223,11 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? GSSS_CS_WAVES : GSSS_CS_WAVES
                 u[4 * iq + 2] = (c0 + 2 < d) ? z2 : 0.0;
                 u[4 * iq + 3] = (c0 + 3 < d) ? z3 : 0.0;
                 publish_extra(e, w);
-                if (Q > 1) __builtin_amdgcn_sched_barrier(0);  // one round at a time
+                if (Q > 1) {  // one round at a time, finished: left alone the compiler sinks the last operations of every
+                              // round's Box-Muller pairs to their first use and keeps ~18 intermediates per round alive
+                    asm volatile("" : "+v"(u[4 * iq + 0]), "+v"(u[4 * iq + 1]), "+v"(u[4 * iq + 2]), "+v"(u[4 * iq + 3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             pref = 2 * (L * Q - nq - 1);
             if (pref < 0) {  // every lane holds normals: block 0 and the first tries take a round of their own
@@ -276,7 +287,10 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? GSSS_CS_WAVES : GSSS_CS_WAVES
                 }
             }
 #pragma unroll
-            for (int i = 0; i < N; ++i) u[i] *= rnw;
+            for (int i = 0; i < N; ++i) {
+                u[i] *= rnw;
+                if (kParkU) upark[(size_t)i * kBlock] = u[i];
+            }
         }
         wave_sync();
         // threshold and margin (Curve32).  The level of x in single precision: the value the accepted try of the previous
@@ -399,7 +413,7 @@ __global__ void __launch_bounds__(kBlock, Q <= 2 ? GSSS_CS_WAVES : GSSS_CS_WAVES
         fm::sincos_tab(th_acc, tab, sn, cs);
         if (alive) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
+            for (int i = 0; i < N; ++i) x[i] = fma(sn, kParkU ? upark[(size_t)i * kBlock] : u[i], cs * x[i]);
             if (kRecur && g == 0) {
 #pragma unroll
                 for (int r = 0; r < NK; ++r) coef[r] = fma(cs, coef[r], sn * coef[NK + r]);  // a . x' = c a.x + s a.u
