@@ -241,7 +241,8 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
             u_th0 = scr[1];
         }
         // ---------------- u = spherical_projection(z, x)   (sphere.py:29-33)
-        const double rnx = inv_norm(vdot<V>(x, x));
+        const double xx = vdot<V>(x, x);
+        const double rnx = inv_norm(xx);
         const double cz = vdot<V>(u, x) * rnx;
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
         }
         e_c = e_eval;
         if (a.screen == 2) q[2 * NK + 1] = INFINITY;  // verification: every try is left to the double-precision decision
-        if (alive && !finite) {
+        if (alive && (!finite || !(xx < INFINITY))) {  // (a NaN state: the clipped level of the curve swallows it, so x.x is looked at)
             err |= GSSS_CHAIN_NONFINITE;
             alive = false;
         }

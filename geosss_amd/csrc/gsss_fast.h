@@ -489,8 +489,11 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             dr.normals(cur.u, 0);
             dr.block(0u, u_thr, u_th0);
         }
+        bool x_ok;
         {  // u = spherical_projection(z, x), sphere.py:29-33, with reciprocals instead of divisions
-            const double rnx = inv_norm(vdot<V>(cur.x, cur.x));
+            const double xx = vdot<V>(cur.x, cur.x);
+            x_ok = xx < INFINITY;  // a NaN / Inf state: the curve's clipped level swallows NaN (v_max), so the state itself is looked at
+            const double rnx = inv_norm(xx);
             double cz = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) cz = fma(cur.u[j], cur.x[j] * rnx, cz);
@@ -518,7 +521,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         }
         cur.t = 0;
         cur.status = kReady;
-        if (!finite) {
+        if (!finite || !x_ok) {
             cur.err |= GSSS_CHAIN_NONFINITE;
             cur.status = kDone;
         }
@@ -1081,8 +1084,11 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
             dr.normals(u, g);
             dr.block(0u, u_thr, u_th0);
         }
+        bool x_ok;  // a NaN / Inf state: flagged (the curve's clipped level would swallow it)
         {   // u = spherical_projection(z, x)   (sphere.py:29-33)
-            const double rnx = inv_norm(vdot<V>(x, x));
+            const double xx = vdot<V>(x, x);
+            x_ok = xx < INFINITY;
+            const double rnx = inv_norm(xx);
             const double cz = vdot<V>(u, x) * rnx;
 #pragma unroll
             for (int i = 0; i < V::N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);
@@ -1120,7 +1126,7 @@ __global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, Run
             thr = lvl0 + fm::log_fast(u_thr);
             finite = lvl0 > -INFINITY && lvl0 < INFINITY;
         }
-        if (!finite) {
+        if (!finite || !x_ok) {
             err |= GSSS_CHAIN_NONFINITE;
             break;
         }
@@ -1341,8 +1347,11 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
             }
         }
         }
+        bool x_ok;  // a NaN / Inf state: flagged (the curve's clipped level would swallow it)
         {   // u = spherical_projection(z, x)
-            const double rnx = inv_norm(vdot<V>(x, x));
+            const double xx = vdot<V>(x, x);
+            x_ok = xx < INFINITY;
+            const double rnx = inv_norm(xx);
             double cz = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) cz = fma(u[j], x[j] * rnx, cz);
@@ -1362,7 +1371,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
             thr = lvl0 + fm::log_fast(u_thr);
             finite = lvl0 > -INFINITY && lvl0 < INFINITY;
         }
-        if (!finite) {
+        if (!finite || !x_ok) {
             err |= GSSS_CHAIN_NONFINITE;
             break;
         }

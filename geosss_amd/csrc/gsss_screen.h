@@ -545,8 +545,11 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
             dr.normals(cur.u, 0);
             dr.block(0u, u_thr, u_th0);
         }
+        bool x_ok;
         {  // u = spherical_projection(z, x), sphere.py:29-33
-            const double rnx = inv_norm(vdot<V>(cur.x, cur.x));
+            const double xx = vdot<V>(cur.x, cur.x);
+            x_ok = xx < INFINITY;  // a NaN / Inf state: the curve's clipped level swallows NaN (v_max), so the state itself is looked at
+            const double rnx = inv_norm(xx);
             double cz = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) cz = fma(cur.u[j], cur.x[j] * rnx, cz);
@@ -567,7 +570,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         }
         cur.t = 0;
         cur.status = kReady;
-        if (!finite) {
+        if (!finite || !x_ok) {
             cur.err |= GSSS_CHAIN_NONFINITE;
             cur.status = kDone;
         }

@@ -274,6 +274,7 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
         }
         // ---------------- u = spherical_projection(z, x)   (sphere.py:29-33)
         double rnx, cz;
+        bool x_ok;  // a NaN / Inf state: flagged (the curve's clipped level would swallow it)
         {
             double pxx = fma(x[0], x[0], fma(x[1], x[1], fma(x[2], x[2], x[3] * x[3])));
             double pzx = fma(u[0], x[0], fma(u[1], x[1], fma(u[2], x[2], u[3] * x[3])));
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
             const double t = group_sum<16>(pxx + pzx);
             const double xx = lane_broadcast(t, 0) + lane_broadcast(t, 16);
             const double zx = lane_broadcast(t, 32) + lane_broadcast(t, 48);
+            x_ok = xx < INFINITY;
             rnx = inv_norm(xx);
             cz = zx * rnx;
         }
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
             for (int i = 0; i < 4; ++i) u[i] *= rnw;
         }
         const double lvl0 = refresh ? level_row(1.0, 0.0) : lvl;
-        if (!(lvl0 > -INFINITY && lvl0 < INFINITY)) {
+        if (!(lvl0 > -INFINITY && lvl0 < INFINITY) || !x_ok) {
             err |= GSSS_CHAIN_NONFINITE;
             break;
         }

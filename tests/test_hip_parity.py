@@ -234,6 +234,39 @@ def test_error_reporting(gs):
         gs.ShrinkageSphericalSliceSampler(big, np.eye(200)[0], 1, mode="fast").advance(1)
 
 
+@pytest.mark.parametrize("d", [10, 50, 200])
+def test_group_speculative_curve_kernel_error_paths(gs, oracle, d):
+    """The group-speculative curve kernel (packed fast mode, d >= 9): max_tries, a NaN state and a replay stream that runs
+    out flag the chain concerned -- and only it --, counters stay consistent, nothing spins."""
+    z = golden(f"traj_curve_d{d}_kappa800.npz")
+    pdf = product_target(z)
+    n = 40
+    x0 = gs.sample_sphere(d - 1, n, seed=4)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, 2, mode="fast", placement="packed", max_tries=3)
+    assert s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0, 1).decode().startswith("curvespec_kernel")
+    s.advance(30)
+    assert np.any(s.errors & 1) and np.all((s.errors & ~1) == 0)          # kappa = 800 needs ~7 tries a step: some chains give up
+    ok = s.errors == 0
+    assert np.all(s.n_tries_per_chain[ok] <= 3 * 30) and np.all(s.n_tries_per_chain[ok] >= 30)
+    bad = np.array(x0)
+    bad[7, 1] = np.nan                                                    # one NaN component: every kernel family flags it
+    for kw in (dict(mode="fast", placement="packed"), dict(mode="fast", placement="packed", screen=False),
+               dict(mode="fast", placement="spread"), dict(mode="exact", placement="packed")):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, bad, 2, **kw)
+        s.advance(4)
+        assert s.errors[7] & 2 and np.all(np.delete(s.errors, 7) == 0), kw
+    # replay: chain 0 has the reference's full stream, chain 1 a truncated one
+    m = 12
+    need = int(z["step_draw_offset"][m])
+    full = np.stack([z["draws"][:need], z["draws"][:need]])
+    t = gs.ShrinkageSphericalSliceSampler(pdf, np.stack([z["x0"], z["x0"]]), 1, mode="fast", placement="packed")
+    t.advance(m, replay=full)
+    assert np.all(t.errors == 0) and np.max(np.abs(t.state - z["states"][m])) < TOL
+    t = gs.ShrinkageSphericalSliceSampler(pdf, z["x0"], 1, mode="fast", placement="packed")
+    t.advance(m, replay=z["draws"][None, : need - 2])
+    assert t.errors[0] & 4
+
+
 def test_layout_round_trip(gs):
     import torch
     lib = gs._lib.load()
@@ -258,7 +291,12 @@ SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16
          ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10),
          # any K <= 16 at any d: component buckets with exact padding (MixtureModel takes any K, distributions.py:209-227)
          ("curve", 9, 4), ("curve", 10, 12), ("curve", 7, 10), ("curve", 30, 16), ("curve", 50, 6), ("curve", 100, 15), ("curve", 3, 2),
-         ("vmf", 3, 7), ("vmf", 6, 3), ("vmf", 8, 13), ("vmf", 9, 16), ("vmf", 4, 1), ("vmf", 7, 4), ("vmf", 30, 7), ("vmf", 100, 12)]
+         ("vmf", 3, 7), ("vmf", 6, 3), ("vmf", 8, 13), ("vmf", 9, 16), ("vmf", 4, 1), ("vmf", 7, 4), ("vmf", 30, 7), ("vmf", 100, 12),
+         # the group-speculative curve kernel's layout boundaries (lanes per chain 4 | 16 at d = 16 | 17, quads per lane at
+         # d = 64 | 65, 128 | 129, 192 | 193, 256; knot builds 10 | 17; every lane holding normals: d = 13 .. 16, 61 .. 64)
+         ("curve", 9, 2), ("curve", 13, 10), ("curve", 16, 10), ("curve", 17, 3), ("curve", 12, 16), ("curve", 61, 10),
+         ("curve", 64, 11), ("curve", 65, 10), ("curve", 128, 5), ("curve", 129, 10), ("curve", 192, 17), ("curve", 193, 10),
+         ("curve", 256, 10)]
 
 
 @pytest.mark.parametrize("kind,d,k", SYNTH)
