@@ -14,9 +14,9 @@ from .mcmc import (IndependenceSampler, MetropolisHastings, MixtureRWMHIndepende
                    ShrinkageSphericalSliceSampler, SphericalHMC, determine_burnin)
 from .registration import CoherentPointDrift, GaussianMixtureModel, PointCloud, RotationProjection
 from .sphere import sample_sphere, sample_sphere_device
-from .utils import SamplerLauncher, count_calls, counter
+from .utils import SamplerLauncher, count_calls, counter, take_time
 
 __all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
-           "MetropolisHastings", "SphericalHMC", "IndependenceSampler", "MixtureRWMHIndependenceSampler", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter",
+           "MetropolisHastings", "SphericalHMC", "IndependenceSampler", "MixtureRWMHIndependenceSampler", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter", "take_time",
            "sphere", "diagnostics", "registration", "CoherentPointDrift", "GaussianMixtureModel", "PointCloud", "RotationProjection", "IAT", "acf", "acf_fft", "distance", "n_eff"]

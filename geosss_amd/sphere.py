@@ -60,3 +60,9 @@ def sample_sphere(d=2, size=None, seed=None, device=None, rng="auto"):
         return x / norm if x.ndim == 1 else x / norm[:, None]
     x = sample_sphere_device(d, n, seed=0 if seed is None else seed, device=device).T.contiguous().cpu().numpy()
     return x[0] if size is None else x
+
+
+def distance(x, y):
+    """Great-circle distance, `geosss.sphere.distance` (sphere.py:64-68): see diagnostics.distance (host or device arrays)."""
+    from .diagnostics import distance as _distance
+    return _distance(x, y)

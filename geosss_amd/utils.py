@@ -1,9 +1,31 @@
 """Launcher + call counter with the reference's names (geosss/utils.py:137-232): the two geodesic slice samplers
 and the two baselines the paper compares them with (RWMH, spherical HMC)."""
+import contextlib
+import logging
+import time
+
 from .distributions import counted
 from .mcmc import MetropolisHastings, RejectionSphericalSliceSampler, ShrinkageSphericalSliceSampler, SphericalHMC
 
 count_calls = counted
+
+
+@contextlib.contextmanager
+def take_time(desc, mute=False):
+    """`with take_time("sss-shrink"): ...` as the reference's scripts time their sampler runs (utils.py:42-48, e.g.
+    scripts/curve_vMF.py:103).  The reference logs CPU process time; the work here happens on the device, so the block is
+    bracketed by device synchronisation and the WALL time is logged (same message format, `logging.info`)."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    yield
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not mute:
+        scale, unit = next(((s, u) for s, u in ((1.0, "s"), (1e-3, "ms"), (1e-6, "us"), (1e-9, "ns")) if dt > s or dt == 0), (1e-9, "ns"))
+        logging.info("%s took %.1f %s", desc, dt / scale, unit)
 
 
 def counter(method_names):

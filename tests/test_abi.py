@@ -130,3 +130,19 @@ def test_seed_argument_handling():
         gs.ShrinkageSphericalSliceSampler(pdf, np.eye(3), [1, 2, 3])
     with pytest.raises(ValueError):
         gs.ShrinkageSphericalSliceSampler(pdf, np.eye(3), 1, rng="mt19937")
+
+
+def test_script_conveniences(caplog):
+    """What the reference's scripts reach for next to the samplers: `gs.take_time` (utils.py:42-48; wall time around a
+    synchronised block here) and `gs.sphere.distance` (sphere.py:64-68)."""
+    import logging
+    import geosss_amd as gs
+    with caplog.at_level(logging.INFO):
+        with gs.take_time("demo"):
+            pass
+        with gs.take_time("quiet", mute=True):
+            pass
+    assert any(r.getMessage().startswith("demo took ") for r in caplog.records)
+    assert not any("quiet" in r.getMessage() for r in caplog.records)
+    d = gs.sphere.distance(np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0]]))
+    assert np.allclose(d, [np.pi / 2, 0.0])
