@@ -62,6 +62,10 @@ __device__ __forceinline__ float log2_32(double v)
 //   level_exact(cf, c, s)      the double-precision level fast_kernel compares with that threshold
 // and the two fused forms the kernel calls (a target may build them without ever holding a whole Coef in registers):
 //   setup32(x, u, U, q)        = coeffs + make32
+//   kParkSkip, refill(x, u, q) the first kParkSkip floats of q are NOT parked with a chain's second state: refill() forms
+//                              them again from x and u when the chain is taken up (same operations, same bits).  Wide
+//                              mixtures: 2 K floats = 40 % of the parked state, one more workgroup per CU without them
+//   kMinWaves                  wavefronts per SIMD the kernel is built for (__launch_bounds__)
 //   decide(x, u, U, c, s)      = level_exact(c, s) > threshold, the all-double decision of an undecided try
 // ------------------------------------------------------------------------------------------
 template <int D, int KC>
@@ -69,6 +73,27 @@ struct ScreenVmf : FastVmf<D, KC> {
     using Base = FastVmf<D, KC>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 3 * KC + 1;
+    // K >= 6: mu_k.x and mu_k.u in single precision (2 K floats) are formed again at take-up instead of being parked:
+    // 18 instead of 28 words of parked state at K = 10, three workgroups per CU instead of two (and the register budget
+    // of three wavefronts per SIMD asked of the compiler: 170 -> 168)
+    static constexpr int kParkSkip = KC >= 6 ? 2 * KC : 0;
+    static constexpr int kMinWaves = KC >= 6 ? 3 : 1;
+    __device__ __forceinline__ void refill(const double (&x)[D], const double (&u)[D], float (&q)[kCoef32Floats]) const
+    {
+        constexpr double L = 1.4426950408889634074;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {  // the operations of coeffs() and make32(), hence their bits
+            double ax = 0.0, au = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double mkj = this->mu[k * D + j];
+                ax = fma(mkj, x[j], ax);
+                au = fma(mkj, u[j], au);
+            }
+            q[k] = (float)(ax * L);
+            q[KC + k] = (float)(au * L);
+        }
+    }
 
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
@@ -166,6 +191,8 @@ struct ScreenBingham : FastBingham<D> {
     using Base = FastBingham<D>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 6;
+    static constexpr int kParkSkip = 0, kMinWaves = 1;
+    __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
         (void)this->make(cf, x, u, 0.0, true);
@@ -329,6 +356,8 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Base = FastCurve<D, NK>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
+    static constexpr int kParkSkip = 0, kMinWaves = 1;
+    __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     Curve32<NK> c32;
     __host__ __device__ static size_t lds_doubles() { return Base::lds_doubles() + 2 * (size_t)(NK - 1); }
     __device__ void stage(double *lds, const TargetBlock &tb)
@@ -420,6 +449,8 @@ struct ScreenCurve : FastCurve<D, NK> {
 template <int D, class TP>
 struct ScreenChain {
     static constexpr int kQ = TP::kCoef32Floats + (TP::kCoef32Floats & 1);  // padded to whole 64-bit words
+    static constexpr int kSkip = TP::kParkSkip;                              // leading floats of q that are not parked
+    static_assert(kSkip % 2 == 0, "whole words");
     double x[D], u[D];
     double lo, hi;
     double thr;   // the step's uniform U of the threshold (mcmc.py:389); the threshold itself is formed on demand
@@ -427,7 +458,7 @@ struct ScreenChain {
     float q[kQ];
     uint32_t n_try;
     int32_t steps_done, row, t, status, err, cursor;
-    static constexpr int kWordsNoReplay = 2 * D + 4 + kQ / 2 + 2;
+    static constexpr int kWordsNoReplay = 2 * D + 4 + (kQ - kSkip) / 2 + 2;
     static constexpr int kWords = kWordsNoReplay + 1;
 };
 
@@ -454,7 +485,7 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
 
 // (measured: asking for two wavefronts per SIMD at d = 10 makes the curve kernel spill 73 registers: 45 -> 64 ms)
 template <int D, class TP, bool REPLAY, bool STATS = false>
-__global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
     using Chain = ScreenChain<D, TP>;
@@ -669,7 +700,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         word(cur.thr);
         word(cur.aux);
 #pragma unroll
-        for (int i = 0; i < Chain::kQ; i += 2) {
+        for (int i = Chain::kSkip; i < Chain::kQ; i += 2) {
             lds_trade(cur.q[i], cur.q[i + 1], p);
             p += kBlock;
         }
@@ -689,6 +720,9 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         cur.err = (int32_t)((uint32_t)packed >> 28);
         parked_status = st;
         slot ^= 1;
+        // the chain taken up tries next -- or may, if its undecided try is decided a rejection: its unparked coefficients
+        // are formed again (a chain that waits for set-up or for its move gets new ones there / needs none)
+        if (Chain::kSkip > 0 && (cur.status == kReady || cur.status == kFinalDecide)) tp.refill(cur.x, cur.u, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
     };
 
     auto flush = [&]() {
@@ -723,7 +757,7 @@ __global__ void __launch_bounds__(kBlock) screened_kernel(TargetBlock tb, RunBlo
         put(cur.thr);
         put(cur.aux);
 #pragma unroll
-        for (int i = 0; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
+        for (int i = Chain::kSkip; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
         put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
         if (REPLAY) put2((uint32_t)cur.cursor, 0u);
         put2(cur.n_try, (uint32_t)pack_flags());
