@@ -27,7 +27,12 @@
 
 namespace gsss {
 
-enum : int32_t { kFinalAccept = 3, kFinalDecide = 4 };  // try stopped at theta = aux: accepted for sure / double precision decides
+// A try that stopped: accepted for sure / double precision decides.  Its theta rests in the end of the bracket it would
+// become were it rejected (mcmc.py:400: lo for theta < 0, else hi) -- the other end is dead if it is accepted and unchanged
+// if it is not -- and the status says which end: + kFinalInHi.  (No word of its own in a chain's parked state.)
+enum : int32_t { kFinalAccept = 3, kFinalDecide = 4, kFinalInHi = 2 };
+__device__ __forceinline__ bool is_final(int32_t st) { return st >= kFinalAccept; }
+__device__ __forceinline__ bool is_decide(int32_t st) { return st == kFinalDecide || st == kFinalDecide + kFinalInHi; }
 
 // |v_cos_f32(fl32(theta / 2 pi)) - cos(theta)| for |theta| <= 2 pi: 1.254e-7 from the hardware (exhaustive sweep)
 // + 2 pi 2^-25 from rounding the argument (in revolutions, |t| <= 1) to single precision; same for sin
@@ -454,11 +459,10 @@ struct ScreenChain {
     double x[D], u[D];
     double lo, hi;
     double thr;   // the step's uniform U of the threshold (mcmc.py:389); the threshold itself is formed on demand
-    double aux;   // kFinal*: theta of the stopped try
     float q[kQ];
     uint32_t n_try;
     int32_t steps_done, row, t, status, err, cursor;
-    static constexpr int kWordsNoReplay = 2 * D + 4 + (kQ - kSkip) / 2 + 2;
+    static constexpr int kWordsNoReplay = 2 * D + 3 + (kQ - kSkip) / 2 + 2;
     static constexpr int kWords = kWordsNoReplay + 1;
 };
 
@@ -532,7 +536,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         if (sum < cur.n_try) cur.err |= GSSS_CHAIN_COUNTER_SATURATED;
         cur.n_try = sum < cur.n_try ? 0xFFFFFFFFu : sum;
     };
-    auto needs_service = [](int32_t st) { return st == kPending || st == kFinalAccept || st == kFinalDecide; };
+    auto needs_service = [](int32_t st) { return st == kPending || is_final(st); };
 
     auto init = [&]() {
         const int32_t c = chain_id();
@@ -544,7 +548,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         for (int j = 0; j < D; ++j) cur.u[j] = 0.0;
 #pragma unroll
         for (int i = 0; i < Chain::kQ; ++i) cur.q[i] = 0.0f;
-        cur.lo = cur.hi = cur.thr = cur.aux = 0.0;
+        cur.lo = cur.hi = cur.thr = 0.0;
         cur.n_try = 0u;
         cur.steps_done = 0;
         cur.row = 0;
@@ -634,11 +638,11 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
                     sincos_rev32(theta, s32, c32);
                     const int verdict = tp.screen(reinterpret_cast<const float (&)[TP::kCoef32Floats]>(cur.q), c32, s32);
                     // (selects, not branches: four exec-mask regions per try otherwise)
-                    const bool rej = verdict < 0, neg = theta < 0.0;
-                    cur.lo = (rej & shrink & neg) ? theta : cur.lo;   // mcmc.py:400
-                    cur.hi = (rej & shrink & !neg) ? theta : cur.hi;
-                    cur.aux = rej ? cur.aux : theta;
-                    cur.status = rej ? cur.status : (verdict > 0 ? kFinalAccept : kFinalDecide);
+                    // a rejected try shrinks the bracket (mcmc.py:400); a stopped one leaves theta in the end it would become
+                    const bool rej = verdict < 0, neg = theta < 0.0, moves = !rej | shrink;
+                    cur.lo = (moves & neg) ? theta : cur.lo;
+                    cur.hi = (moves & !neg) ? theta : cur.hi;
+                    cur.status = rej ? cur.status : ((verdict > 0 ? kFinalAccept : kFinalDecide) + (neg ? 0 : kFinalInHi));
                     stopped = !rej;
                 }
             }
@@ -651,11 +655,11 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
 
     // the double-precision part of a stopped try: decide it if the screen could not, then move (mcmc.py:396-399)
     auto finalise = [&]() {
-        const double theta = cur.aux;
+        const double theta = cur.status >= kFinalAccept + kFinalInHi ? cur.hi : cur.lo;
         double sn, cs;
         fm::sincos_tab(theta, tab, sn, cs);
         bool accepted = true;
-        if (cur.status == kFinalDecide) {  // rare: the double-precision test itself (mcmc.py:389, 397)
+        if (is_decide(cur.status)) {  // rare: the double-precision test itself (mcmc.py:389, 397)
             accepted = tp.decide(cur.x, cur.u, cur.thr, cs, sn);
         }
         if (accepted) {
@@ -674,12 +678,8 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
             const bool exhausted = REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
             cur.status = (cur.steps_done < n_steps && !exhausted) ? kPending : kDone;
         } else {
-            if (shrink) {  // mcmc.py:400
-                if (theta < 0.0)
-                    cur.lo = theta;
-                else
-                    cur.hi = theta;
-            }
+            // mcmc.py:400: the bracket already ends at theta; the rejection sampler's fixed bracket (0, 2 pi) is restored
+            if (!shrink) cur.hi = kTwoPi;
             cur.status = kReady;
         }
     };
@@ -698,7 +698,6 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         word(cur.lo);
         word(cur.hi);
         word(cur.thr);
-        word(cur.aux);
 #pragma unroll
         for (int i = Chain::kSkip; i < Chain::kQ; i += 2) {
             lds_trade(cur.q[i], cur.q[i + 1], p);
@@ -722,7 +721,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         slot ^= 1;
         // the chain taken up tries next -- or may, if its undecided try is decided a rejection: its unparked coefficients
         // are formed again (a chain that waits for set-up or for its move gets new ones there / needs none)
-        if (Chain::kSkip > 0 && (cur.status == kReady || cur.status == kFinalDecide)) tp.refill(cur.x, cur.u, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
+        if (Chain::kSkip > 0 && (cur.status == kReady || is_decide(cur.status))) tp.refill(cur.x, cur.u, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
     };
 
     auto flush = [&]() {
@@ -755,7 +754,6 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         put(cur.lo);
         put(cur.hi);
         put(cur.thr);
-        put(cur.aux);
 #pragma unroll
         for (int i = Chain::kSkip; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
         put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
@@ -783,7 +781,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         const bool service = pend != 0ull && (4 * __popcll(waiting) >= 3 * n_live || 8 * __popcll(pend) >= 7 * n_live);
         if (service) {
             if (kPark && !needs_service(cur.status) && needs_service(parked_status)) trade();  // bring the waiting chain in
-            if (cur.status == kFinalAccept || cur.status == kFinalDecide) finalise();
+            if (is_final(cur.status)) finalise();
             if (cur.status == kPending) setup();
         }
         if (trying == 0ull && !service && __ballot(kPark && cur.status != kReady && parked_status == kReady) == 0ull) {
