@@ -64,9 +64,11 @@ def algorithmic_flops(name, d, tries_per_step):
     """FP64 flops (FMA = 2) of the restricted-form algorithm per chain-step, counted from the kernels'
     arithmetic (DESIGN.md "Roofline"): per step the d normals (one Box-Muller pair = 80: log 40, sincos 36,
     sqrt + scalings), the projection (3 dots, 2 axpys, 2 rsqrt-scalings = 10 d + 20), the coefficients of the
-    great circle, the level of x and log U; per try sincos (36) + the level of y(theta) + bracket update."""
+    great circle, the level of x and log U; per try sincos (36) + the level of y(theta) + bracket update.
+    On S^2 (d = 3) the library stream draws the unit tangent directly: x / |x| (13), one sincos (36),
+    the orthonormal basis of the tangent plane (22) and the combination (9) instead of two pairs and the projection."""
     pairs = (d + 1) // 2
-    setup = 80.0 * pairs + 10.0 * d + 20.0
+    setup = 80.0 if d == 3 else 80.0 * pairs + 10.0 * d + 20.0
     if name.startswith("vmfmix"):
         k = 3 if name == "vmfmix_readme" else 10
         setup += 4.0 * k * d + 34.0 * k              # K dots with x and u; K exps for the level of x

@@ -189,6 +189,24 @@ __device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, const fm:
     z1 = r * s;
 }
 
+// Philox stream on S^2 (d = 3): the unit tangent u at x is drawn directly -- an angle phi in the tangent plane, ONE 32-bit
+// word of block 1 -- instead of three normals projected and normalised (sphere.py:29-33, mcmc.py:387: the direction of the
+// projected normal vector is uniform on the tangent circle, so the chain's law is the same; the replayed and the numpy
+// streams keep the reference's normals).  n = x / |x|; (b1, b2) the branch-free orthonormal basis of the tangent plane of
+// Duff et al., "Building an Orthonormal Basis, Revisited" (JCGT 2017); u = cos(phi) b1 + sin(phi) b2, unit and orthogonal
+// to n to rounding.  The oracle forms the same expressions (gor_tangent3).
+__device__ __forceinline__ void tangent3(double n0, double n1, double n2, double sn, double cs, double &u0, double &u1, double &u2)
+{
+    const double s = copysign(1.0, n2);
+    const double a = -1.0 / (s + n2);
+    const double b = n0 * n1 * a;
+    const double b10 = 1.0 + s * n0 * n0 * a, b11 = s * b, b12 = -s * n0;
+    const double b20 = b, b21 = s + n1 * n1 * a, b22 = -n1;
+    u0 = fma(sn, b20, cs * b10);
+    u1 = fma(sn, b21, cs * b11);
+    u2 = fma(sn, b22, cs * b12);
+}
+
 // LDS doubles a kernel sets aside for fm::Tables (16-byte aligned inside the dynamic LDS block)
 constexpr int kTabLds = fm::kTableDoubles + 2;
 __device__ __forceinline__ fm::Tables stage_tables(double *lds_after_params)
@@ -354,6 +372,28 @@ struct PhiloxDraws {
                 if (4 * iq + i < V::N) z[4 * iq + i] = (c0 + i < d) ? zz[i] : 0.0;
         }
     }
+    // d = 3: the unit tangent at n = x / |x| from word 0 of block 1 (tangent3); lanes that hold no component keep zeros
+    static constexpr bool kTangent3 = true;
+    __device__ __forceinline__ void tangent(const double (&nrm)[V::N], double (&u)[V::N], int g) const
+    {
+        if constexpr (V::N >= 3) {
+            uint32_t w[4];
+            words(1u, w);
+            double sn, cs;
+            if constexpr (TAB)
+                fm::sincos_word_tab(w[0], tab, sn, cs);
+            else
+                fm::sincos_2pi((double)w[0] * 0x1.0p-32, sn, cs);
+            double t0, t1, t2;
+            tangent3(nrm[0], nrm[1], nrm[2], sn, cs, t0, t1, t2);
+            const bool mine = V::comp(g, 0) == 0;
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) u[i] = 0.0;
+            u[0] = mine ? t0 : 0.0;
+            u[1] = mine ? t1 : 0.0;
+            u[2] = mine ? t2 : 0.0;
+        }
+    }
     __device__ __forceinline__ void step_uniforms(double &u_thr, double &u_theta0, bool /*need_theta0*/) const
     {
         block(0u, u_thr, u_theta0);
@@ -439,6 +479,8 @@ struct ReplayDraws {
         u_thr = take();
         u_theta0 = need_theta0 ? take() : 0.0;
     }
+    static constexpr bool kTangent3 = false;  // the reference's own draws: d normals
+    __device__ __forceinline__ void tangent(const double (&)[V::N], double (&)[V::N], int) const {}
     __device__ __forceinline__ double next_try() { return take(); }
     __device__ __forceinline__ double chi(int) { return sqrt(2.0 * take()); }  // the recorded gamma(d/2) variate
     __device__ __forceinline__ double accept_uniform() { return take(); }
@@ -560,6 +602,8 @@ struct NumpyDraws {
         u_thr = next_double();
         u_theta0 = need_theta0 ? next_double() : 0.0;
     }
+    static constexpr bool kTangent3 = false;  // the reference's own draws: d normals
+    __device__ __forceinline__ void tangent(const double (&)[V::N], double (&)[V::N], int) const {}
     __device__ __forceinline__ double next_try() { return next_double(); }
     // Generator.gamma(shape), shape > 1: numpy's random_standard_gamma (Marsaglia-Tsang on the ziggurat normals)
     __device__ double standard_gamma(double shape)
@@ -883,8 +927,14 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
 
         // u = spherical_projection(z, x)   (sphere.py:29-33)
         double u[V::N];
-        dr.normals(u, g);  // u holds z for now
-        {
+        if (Draws::kTangent3 && d == 3) {  // Philox stream on S^2: the unit tangent is drawn directly (tangent3)
+            const double nx = sqrt(vdot<V>(x, x)) + 1e-100;
+            double nrm[V::N];
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) nrm[i] = x[i] / nx;
+            dr.tangent(nrm, u, g);
+        } else {
+            dr.normals(u, g);  // u holds z for now
             const double nx = sqrt(vdot<V>(x, x)) + 1e-100;
             double nrm[V::N];
 #pragma unroll

@@ -577,10 +577,17 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
             u_th0 = shrink ? replay_take() : 0.0;
         } else {
             const PhiloxDraws<V, true> dr = philox();
-            dr.normals(cur.u, 0);
+            if constexpr (D != 3) dr.normals(cur.u, 0);
             dr.block(0u, u_thr, u_th0);
         }
         bool x_ok;
+        if constexpr (D == 3 && !REPLAY) {  // Philox stream on S^2: the unit tangent is drawn directly (tangent3, gsss_device.h)
+            const double xx = vdot<V>(cur.x, cur.x);
+            x_ok = xx < INFINITY;
+            const double rnx = inv_norm(xx);
+            const double nrm[3] = {cur.x[0] * rnx, cur.x[1] * rnx, cur.x[2] * rnx};
+            philox().tangent(nrm, cur.u, 0);
+        } else
         {  // u = spherical_projection(z, x), sphere.py:29-33
             const double xx = vdot<V>(cur.x, cur.x);
             x_ok = xx < INFINITY;  // a NaN / Inf state: the curve's clipped level swallows NaN (v_max), so the state itself is looked at

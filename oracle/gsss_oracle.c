@@ -502,6 +502,27 @@ static void gor_draw_normals(gor_draws *g, double *z)
     }
 }
 
+/* Library stream (Philox) on S^2, d = 3: the unit tangent u at x is drawn directly -- an angle phi in the tangent plane
+ * from word 0 of block 1 -- instead of three normals projected and normalised (sphere.py:29-33 has the same law: the
+ * direction of the projected normal vector is uniform on the tangent circle).  n = x / |x|, (b1, b2) the branch-free
+ * orthonormal basis of Duff et al. 2017, u = cos(phi) b1 + sin(phi) b2: the expressions of tangent3 in gsss_device.h.
+ * The replayed and the numpy streams keep the reference's normals. */
+static void gor_tangent3(const double *x, uint32_t w0, double *u)
+{
+    double n[3];
+    gor_radial_projection(x, 3, n);
+    const double phi = 2.0 * 3.141592653589793 * ((double)w0 * 0x1.0p-32);
+    const double sn = sin(phi), cs = cos(phi);
+    const double s = copysign(1.0, n[2]);
+    const double a = -1.0 / (s + n[2]);
+    const double b = n[0] * n[1] * a;
+    const double b10 = 1.0 + s * n[0] * n[0] * a, b11 = s * b, b12 = -s * n[0];
+    const double b20 = b, b21 = s + n[1] * n[1] * a, b22 = -n[1];
+    u[0] = fma(sn, b20, cs * b10);
+    u[1] = fma(sn, b21, cs * b11);
+    u[2] = fma(sn, b22, cs * b12);
+}
+
 /* the threshold uniform (mcmc.py:389) and theta0 uniform (mcmc.py:391) */
 static void gor_draw_step_uniforms(gor_draws *g, double *u_thr, double *u_theta0, int need_theta0)
 {
@@ -546,8 +567,14 @@ static int gor_step(const gor_target *t, double *x, gor_draws *g, int sampler, i
     const double two_pi = 2.0 * 3.141592653589793; /* 2 * np.pi */
 
     g->try_idx = 0;
-    gor_draw_normals(g, z);                /* mcmc.py:387 */
-    gor_spherical_projection(z, x, d, u);  /* mcmc.py:387 */
+    if (d == 3 && !g->pcg && !g->replay) { /* library stream on S^2: the tangent direction itself (gor_tangent3) */
+        uint32_t w[4];
+        gor_stream_words(g->seed, g->chain, g->step, 1u, w);
+        gor_tangent3(x, w[0], u);
+    } else {
+        gor_draw_normals(g, z);                /* mcmc.py:387 */
+        gor_spherical_projection(z, x, d, u);  /* mcmc.py:387 */
+    }
     double u_thr, u_th0;
     gor_draw_step_uniforms(g, &u_thr, &u_th0, sampler == GOR_SHRINK);
     double px = gor_logprob(t, x);
