@@ -122,7 +122,10 @@ typedef struct gsss_target_desc {
  * Random numbers: counter-based Philox4x32-10 keyed by `seed`; the draws of chain c at
  * step s are a pure function of (seed, chain_offset + c, step_offset + s), so any split of
  * the chains over devices or of the steps over calls reproduces the same numbers
- * (DESIGN.md §3 "Random streams").  If replay_dev is non-NULL the draws are read from it instead:
+ * (DESIGN.md §3 "Random streams").  On this stream a step draws d normals for the tangent direction as the reference does
+ * (mcmc.py:387) -- except on S^2 (d = 3), where the uniformly distributed unit tangent is drawn directly as one angle in
+ * the tangent plane (same law; the two sources below keep the reference's normals).
+ * If replay_dev is non-NULL the draws are read from it instead:
  * per chain `replay_stride` doubles in the order the reference consumes them
  * (d normals, u_threshold, [u_theta0,] u_try, u_try, ... ; next step ...) -- this is how the
  * parity tests reproduce reference chains bit for bit.  A third source, rng_state_dev, is numpy's
