@@ -372,18 +372,26 @@ struct PhiloxDraws {
                 if (4 * iq + i < V::N) z[4 * iq + i] = (c0 + i < d) ? zz[i] : 0.0;
         }
     }
-    // d = 3: the unit tangent at n = x / |x| from word 0 of block 1 (tangent3); lanes that hold no component keep zeros
+    // S^2 (d = 3): block 0 carries the whole set-up of a step -- U_threshold (53 bits: words 0, 1), U_theta0 (32 bits: word 2;
+    // the offset of the bracket, mcmc.py:391) and the angle of the tangent direction (word 3) -- and block 1 is not drawn
     static constexpr bool kTangent3 = true;
-    __device__ __forceinline__ void tangent(const double (&nrm)[V::N], double (&u)[V::N], int g) const
+    __device__ __forceinline__ void step_s2(double &u_thr, double &u_theta0, uint32_t &w_phi) const
+    {
+        uint32_t w[4];
+        words(0u, w);
+        u_thr = u53(w[0], w[1]);
+        u_theta0 = (double)w[2] * 0x1.0p-32;
+        w_phi = w[3];
+    }
+    // the unit tangent at n = x / |x| for the angle word w_phi (tangent3); lanes that hold no component keep zeros
+    __device__ __forceinline__ void tangent(const double (&nrm)[V::N], double (&u)[V::N], int g, uint32_t w_phi) const
     {
         if constexpr (V::N >= 3) {
-            uint32_t w[4];
-            words(1u, w);
             double sn, cs;
             if constexpr (TAB)
-                fm::sincos_word_tab(w[0], tab, sn, cs);
+                fm::sincos_word_tab(w_phi, tab, sn, cs);
             else
-                fm::sincos_2pi((double)w[0] * 0x1.0p-32, sn, cs);
+                fm::sincos_2pi((double)w_phi * 0x1.0p-32, sn, cs);
             double t0, t1, t2;
             tangent3(nrm[0], nrm[1], nrm[2], sn, cs, t0, t1, t2);
             const bool mine = V::comp(g, 0) == 0;
@@ -480,7 +488,8 @@ struct ReplayDraws {
         u_theta0 = need_theta0 ? take() : 0.0;
     }
     static constexpr bool kTangent3 = false;  // the reference's own draws: d normals
-    __device__ __forceinline__ void tangent(const double (&)[V::N], double (&)[V::N], int) const {}
+    __device__ __forceinline__ void step_s2(double &, double &, uint32_t &) const {}
+    __device__ __forceinline__ void tangent(const double (&)[V::N], double (&)[V::N], int, uint32_t) const {}
     __device__ __forceinline__ double next_try() { return take(); }
     __device__ __forceinline__ double chi(int) { return sqrt(2.0 * take()); }  // the recorded gamma(d/2) variate
     __device__ __forceinline__ double accept_uniform() { return take(); }
@@ -603,7 +612,8 @@ struct NumpyDraws {
         u_theta0 = need_theta0 ? next_double() : 0.0;
     }
     static constexpr bool kTangent3 = false;  // the reference's own draws: d normals
-    __device__ __forceinline__ void tangent(const double (&)[V::N], double (&)[V::N], int) const {}
+    __device__ __forceinline__ void step_s2(double &, double &, uint32_t &) const {}
+    __device__ __forceinline__ void tangent(const double (&)[V::N], double (&)[V::N], int, uint32_t) const {}
     __device__ __forceinline__ double next_try() { return next_double(); }
     // Generator.gamma(shape), shape > 1: numpy's random_standard_gamma (Marsaglia-Tsang on the ziggurat normals)
     __device__ double standard_gamma(double shape)
@@ -927,12 +937,15 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
 
         // u = spherical_projection(z, x)   (sphere.py:29-33)
         double u[V::N];
-        if (Draws::kTangent3 && d == 3) {  // Philox stream on S^2: the unit tangent is drawn directly (tangent3)
+        double u_thr, u_th0;
+        if (Draws::kTangent3 && d == 3) {  // Philox stream on S^2: one block for the step, the unit tangent drawn directly (tangent3)
+            uint32_t w_phi = 0u;
+            dr.step_s2(u_thr, u_th0, w_phi);
             const double nx = sqrt(vdot<V>(x, x)) + 1e-100;
             double nrm[V::N];
 #pragma unroll
             for (int i = 0; i < V::N; ++i) nrm[i] = x[i] / nx;
-            dr.tangent(nrm, u, g);
+            dr.tangent(nrm, u, g, w_phi);
         } else {
             dr.normals(u, g);  // u holds z for now
             const double nx = sqrt(vdot<V>(x, x)) + 1e-100;
@@ -945,9 +958,8 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
             const double nw = sqrt(vdot<V>(u, u)) + 1e-100;
 #pragma unroll
             for (int i = 0; i < V::N; ++i) u[i] = u[i] / nw;
+            dr.step_uniforms(u_thr, u_th0, shrink);
         }
-        double u_thr, u_th0;
-        dr.step_uniforms(u_thr, u_th0, shrink);
         const double thr = px + fm::log_fast(u_thr);  // mcmc.py:389
         double lo, hi;
         if (shrink) {

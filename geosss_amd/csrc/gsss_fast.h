@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     // everything a step needs before its first try (mcmc.py:387-392)
     auto setup = [&]() {
         double u_thr, u_th0;
+        uint32_t w_phi = 0u;  // S^2, Philox stream: the angle word of the tangent direction
         if (REPLAY) {
             if (cur.cursor + D <= (int32_t)a.replay_stride) {
 #pragma unroll
@@ -486,8 +487,12 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             u_th0 = shrink ? replay_take() : 0.0;
         } else {
             const PhiloxDraws<V, true> dr = philox();
-            if constexpr (D != 3) dr.normals(cur.u, 0);
-            dr.block(0u, u_thr, u_th0);
+            if constexpr (D == 3) {
+                dr.step_s2(u_thr, u_th0, w_phi);
+            } else {
+                dr.normals(cur.u, 0);
+                dr.block(0u, u_thr, u_th0);
+            }
         }
         bool x_ok;
         if constexpr (D == 3 && !REPLAY) {  // Philox stream on S^2: the unit tangent is drawn directly (tangent3, gsss_device.h)
@@ -495,7 +500,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             x_ok = xx < INFINITY;
             const double rnx = inv_norm(xx);
             const double nrm[3] = {cur.x[0] * rnx, cur.x[1] * rnx, cur.x[2] * rnx};
-            philox().tangent(nrm, cur.u, 0);
+            philox().tangent(nrm, cur.u, 0, w_phi);
         } else
         {  // u = spherical_projection(z, x), sphere.py:29-33, with reciprocals instead of divisions
             const double xx = vdot<V>(cur.x, cur.x);
@@ -1317,7 +1322,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
 
     for (int64_t s = 0; s < a.n_steps; ++s) {
         double u[D], u_thr, u_th0, pair_u0 = 0.0, pair_u1 = 0.0;
-        uint32_t tangent_word = 0u;  // d = 3, Philox: word 0 of the step's block 1 (in lane 9)
+        uint32_t tangent_word = 0u;  // d = 3, Philox: word 3 of the step's block 0 (in lane 8)
         if (NUMPY) {
             nd.normals(u, 0);                            // mcmc.py:387
             u_thr = nd.next_double();                    // mcmc.py:389
@@ -1332,9 +1337,11 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
         }
         pair_u0 = u53(w[0], w[1]);  // lanes 0-7: tries 2l, 2l+1; lane 8: U_thr, U_theta0
         pair_u1 = u53(w[2], w[3]);
-        tangent_word = w[0];
+        tangent_word = w[3];
         u_thr = lane_broadcast(pair_u0, 8);
         u_th0 = lane_broadcast(pair_u1, 8);
+        if constexpr (D == 3)  // S^2: block 0 carries U_threshold, U_theta0 (32 bits: word 2) and the tangent angle (word 3)
+            u_th0 = (double)(uint32_t)__builtin_amdgcn_readlane((int)w[2], 8) * 0x1.0p-32;
         // ---- normals: Box-Muller pair p on lane p (words of block 1 + p/2, held by lane 9 + p/2)
         if constexpr (D != 3)
         {
@@ -1358,11 +1365,11 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
         }
         }
         bool x_ok;  // a NaN / Inf state: flagged (the curve's clipped level would swallow it)
-        if constexpr (D == 3 && !NUMPY) {  // Philox stream on S^2: the unit tangent from word 0 of block 1 (lane 9), tangent3
+        if constexpr (D == 3 && !NUMPY) {  // Philox stream on S^2: the unit tangent from word 3 of block 0 (lane 8), tangent3
             const double xx = vdot<V>(x, x);
             x_ok = xx < INFINITY;
             const double rnx = inv_norm(xx);
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)tangent_word, 9);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)tangent_word, 8);
             double sn, cs;
             fm::sincos_word_tab(w0, tab, sn, cs);
             tangent3(x[0] * rnx, x[1] * rnx, x[2] * rnx, sn, cs, u[0], u[1], u[2]);

@@ -561,6 +561,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
     // everything a step needs before its first try (mcmc.py:387-392); arithmetic identical to fast_kernel's
     auto setup = [&]() {
         double u_thr, u_th0;
+        uint32_t w_phi = 0u;  // S^2, Philox stream: the angle word of the tangent direction
         if (REPLAY) {
             if (cur.cursor + D <= (int32_t)a.replay_stride) {
 #pragma unroll
@@ -577,8 +578,12 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
             u_th0 = shrink ? replay_take() : 0.0;
         } else {
             const PhiloxDraws<V, true> dr = philox();
-            if constexpr (D != 3) dr.normals(cur.u, 0);
-            dr.block(0u, u_thr, u_th0);
+            if constexpr (D == 3) {
+                dr.step_s2(u_thr, u_th0, w_phi);
+            } else {
+                dr.normals(cur.u, 0);
+                dr.block(0u, u_thr, u_th0);
+            }
         }
         bool x_ok;
         if constexpr (D == 3 && !REPLAY) {  // Philox stream on S^2: the unit tangent is drawn directly (tangent3, gsss_device.h)
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
             x_ok = xx < INFINITY;
             const double rnx = inv_norm(xx);
             const double nrm[3] = {cur.x[0] * rnx, cur.x[1] * rnx, cur.x[2] * rnx};
-            philox().tangent(nrm, cur.u, 0);
+            philox().tangent(nrm, cur.u, 0, w_phi);
         } else
         {  // u = spherical_projection(z, x), sphere.py:29-33
             const double xx = vdot<V>(cur.x, cur.x);

@@ -124,7 +124,8 @@ typedef struct gsss_target_desc {
  * the chains over devices or of the steps over calls reproduces the same numbers
  * (DESIGN.md §3 "Random streams").  On this stream a step draws d normals for the tangent direction as the reference does
  * (mcmc.py:387) -- except on S^2 (d = 3), where the uniformly distributed unit tangent is drawn directly as one angle in
- * the tangent plane (same law; the two sources below keep the reference's normals).
+ * the tangent plane and one block carries the whole set-up of a step (same law; the two sources below keep the reference's
+ * normals and draw order).
  * If replay_dev is non-NULL the draws are read from it instead:
  * per chain `replay_stride` doubles in the order the reference consumes them
  * (d normals, u_threshold, [u_theta0,] u_try, u_try, ... ; next step ...) -- this is how the

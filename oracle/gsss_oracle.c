@@ -503,7 +503,7 @@ static void gor_draw_normals(gor_draws *g, double *z)
 }
 
 /* Library stream (Philox) on S^2, d = 3: the unit tangent u at x is drawn directly -- an angle phi in the tangent plane
- * from word 0 of block 1 -- instead of three normals projected and normalised (sphere.py:29-33 has the same law: the
+ * from word 3 of block 0 -- instead of three normals projected and normalised (sphere.py:29-33 has the same law: the
  * direction of the projected normal vector is uniform on the tangent circle).  n = x / |x|, (b1, b2) the branch-free
  * orthonormal basis of Duff et al. 2017, u = cos(phi) b1 + sin(phi) b2: the expressions of tangent3 in gsss_device.h.
  * The replayed and the numpy streams keep the reference's normals. */
@@ -567,16 +567,20 @@ static int gor_step(const gor_target *t, double *x, gor_draws *g, int sampler, i
     const double two_pi = 2.0 * 3.141592653589793; /* 2 * np.pi */
 
     g->try_idx = 0;
-    if (d == 3 && !g->pcg && !g->replay) { /* library stream on S^2: the tangent direction itself (gor_tangent3) */
+    double u_thr, u_th0;
+    if (d == 3 && !g->pcg && !g->replay) {
+        /* library stream on S^2: block 0 carries the whole set-up of the step -- U_threshold (53 bits: words 0, 1),
+         * U_theta0 (32 bits: word 2), the angle of the tangent direction (word 3, gor_tangent3); block 1 is not drawn */
         uint32_t w[4];
-        gor_stream_words(g->seed, g->chain, g->step, 1u, w);
-        gor_tangent3(x, w[0], u);
+        gor_stream_words(g->seed, g->chain, g->step, 0u, w);
+        u_thr = (double)(((uint64_t)(w[0] >> 5) << 26) | (uint64_t)(w[1] >> 6)) * 0x1.0p-53;
+        u_th0 = (double)w[2] * 0x1.0p-32;
+        gor_tangent3(x, w[3], u);
     } else {
         gor_draw_normals(g, z);                /* mcmc.py:387 */
         gor_spherical_projection(z, x, d, u);  /* mcmc.py:387 */
+        gor_draw_step_uniforms(g, &u_thr, &u_th0, sampler == GOR_SHRINK);
     }
-    double u_thr, u_th0;
-    gor_draw_step_uniforms(g, &u_thr, &u_th0, sampler == GOR_SHRINK);
     double px = gor_logprob(t, x);
     double threshold = px + log(u_thr);    /* mcmc.py:389 */
     if (trace_thr) *trace_thr = threshold;
