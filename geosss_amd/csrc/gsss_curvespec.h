@@ -352,16 +352,22 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
                 }
             }
             double my_theta = 0.0;
+            if (shrink) {  // (two loops: the sampler is the same for the whole launch, a select per end and try otherwise)
 #pragma unroll
-            for (int qq = 0; qq < L; ++qq) {
-                const double ut = REPLAY ? ring[qq] : ring[(t_base + qq) & (kRing - 1)];
-                const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
-                if (g == qq) my_theta = theta;
-                if (shrink) {                               // mcmc.py:400, assuming try qq is rejected
-                    if (theta < 0.0)
-                        lo = theta;
-                    else
-                        hi = theta;
+                for (int qq = 0; qq < L; ++qq) {
+                    const double ut = REPLAY ? ring[qq] : ring[(t_base + qq) & (kRing - 1)];
+                    const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
+                    if (g == qq) my_theta = theta;
+                    const bool neg = theta < 0.0;               // mcmc.py:400, assuming try qq is rejected
+                    lo = neg ? theta : lo;
+                    hi = neg ? hi : theta;
+                }
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < L; ++qq) {
+                    const double ut = REPLAY ? ring[qq] : ring[(t_base + qq) & (kRing - 1)];
+                    const double theta = fma(hi - lo, ut, lo);  // mcmc.py:367, 395: the bracket stays (0, 2 pi)
+                    if (g == qq) my_theta = theta;
                 }
             }
             if (REPLAY) wave_sync();  // the ring is rewritten by the next batch
