@@ -6,12 +6,13 @@ Drop-in for the slice-sampler path of microscopic-image-analysis/geosss:
     pdf = gs.MixtureModel([gs.VonMisesFisher(80.0 * mu) for mu in mus])
     samples = gs.ShrinkageSphericalSliceSampler(pdf, init_state, seed).sample(n_samples, burnin)
 """
-from . import _lib, diagnostics, registration, sphere
+from . import _lib, diagnostics, rand, registration, sphere
 from .diagnostics import IAT, acf, acf_fft, distance, n_eff
 from .distributions import (Bingham, BinghamFisher, CurvedVonMisesFisher, Distribution, MixtureModel, SlerpCurve, VonMisesFisher,
                             brownian_curve, random_bingham)
 from .mcmc import (IndependenceSampler, MetropolisHastings, MixtureRWMHIndependenceSampler, RejectionSphericalSliceSampler,
                    ShrinkageSphericalSliceSampler, SphericalHMC, determine_burnin)
+from .rand import sample_bingham, sample_bingham_2d, sample_bingham_3d, sample_vMF
 from .registration import CoherentPointDrift, GaussianMixtureModel, PointCloud, RotationProjection
 from .sphere import sample_sphere, sample_sphere_device
 from .utils import SamplerLauncher, count_calls, counter, take_time
@@ -19,4 +20,4 @@ from .utils import SamplerLauncher, count_calls, counter, take_time
 __all__ = ["Bingham", "BinghamFisher", "CurvedVonMisesFisher", "Distribution", "MixtureModel", "SlerpCurve", "VonMisesFisher",
            "brownian_curve", "random_bingham", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler",
            "MetropolisHastings", "SphericalHMC", "IndependenceSampler", "MixtureRWMHIndependenceSampler", "determine_burnin", "sample_sphere", "sample_sphere_device", "SamplerLauncher", "count_calls", "counter", "take_time",
-           "sphere", "diagnostics", "registration", "CoherentPointDrift", "GaussianMixtureModel", "PointCloud", "RotationProjection", "IAT", "acf", "acf_fft", "distance", "n_eff"]
+           "sphere", "diagnostics", "registration", "rand", "sample_vMF", "sample_bingham", "sample_bingham_2d", "sample_bingham_3d", "CoherentPointDrift", "GaussianMixtureModel", "PointCloud", "RotationProjection", "IAT", "acf", "acf_fft", "distance", "n_eff"]
