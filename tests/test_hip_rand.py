@@ -52,3 +52,21 @@ def test_sample_bingham_agrees_with_the_slice_sampler(gs):
     with pytest.raises(ValueError):
         gs.sample_bingham_3d(pdf, 5)
     assert gs.sample_bingham_3d(gs.Bingham(np.diag([3.0, 1.0, 0.0])), 7, seed=1).shape == (7, 3)
+
+
+def test_slice_sampler_on_s2_matches_direct_mixture_draws(gs):
+    """The README mixture on S^2, two independent routes to the same distribution: 10^6 shrinkage chains on the library
+    stream (which draws the tangent direction directly on S^2) after 600 steps, and 10^6 exact draws
+    (a component by its weight, then Wood's vMF generator).  First and second moments agree to sampling error."""
+    mus = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
+    pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mus])
+    n = 1_000_000
+    s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere(2, n, seed=3), 17)
+    s.advance(600)
+    X = s.state
+    Y = np.concatenate([gs.sample_vMF(gs.VonMisesFisher(m), n // 3 + (i < n % 3), seed=40 + i) for i, m in enumerate(mus)])
+    assert np.max(np.abs(X.mean(0) - Y.mean(0))) < 5e-3          # chains still carry their start's memory at the 1e-3 level
+    assert np.max(np.abs(X.T @ X / n - Y.T @ Y / len(Y))) < 5e-3
+    r = gs.RejectionSphericalSliceSampler(pdf, gs.sample_sphere(2, 200_000, seed=5), 19)
+    r.advance(300)
+    assert np.max(np.abs(r.state.mean(0) - Y.mean(0))) < 1e-2
