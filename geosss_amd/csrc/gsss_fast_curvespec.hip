@@ -8,12 +8,22 @@ namespace gsss {
 // the lane / cooperative kernels below.
 int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, bool lane, hipStream_t st)
 {
+    // L lanes per chain, Q component quads per lane (d <= 4 Q L), kernels built for 10 and for 17 knots.  Measured at 10^5
+    // chains (tools/bench_curve_sweep.py, 10^9 chain-steps/s): d = 17 .. 32 <4,2> 2.5 against <16,1> 1.7; d = 33 .. 48 <4,3>
+    // 2.2 / 1.6; d = 49 .. 64 <4,4> 2.0 / 1.6 -- the per-step serial work is repeated in 4 instead of 16 lanes, and sixteen
+    // groups share a wavefront.  (<4,4> with 17 knots spills registers: those shapes stay with <16,1>.)
 #define GSSS_SPEC(LL, QQ)                                                                                   \
     do {                                                                                                    \
         if (probe) GSSS_PROBE(lane, "curvespec_kernel<%d, %d, %d>", LL, QQ, tb.k <= 10 ? 10 : 17);          \
         return tb.k <= 10 ? do_curvespec<LL, QQ, 10>(tb, rb, replay, st) : do_curvespec<LL, QQ, 17>(tb, rb, replay, st); \
     } while (0)
     if (tb.d <= 16) GSSS_SPEC(4, 1);
+    if (tb.d <= 32) GSSS_SPEC(4, 2);
+    if (tb.d <= 48) GSSS_SPEC(4, 3);
+    if (tb.d <= 64 && tb.k <= 10) {
+        if (probe) GSSS_PROBE(lane, "curvespec_kernel<4, 4, 10>");
+        return do_curvespec<4, 4, 10>(tb, rb, replay, st);
+    }
     if (tb.d <= 64) GSSS_SPEC(16, 1);
     if (tb.d <= 128) GSSS_SPEC(16, 2);
     if (tb.d <= 192) GSSS_SPEC(16, 3);
