@@ -4,7 +4,8 @@
 // The lane-per-chain kernels hold x, u and 2 NK coefficients of a chain in one lane: from d = 9 on that is more than
 // 256 vector registers (one wavefront per SIMD, and at the 10^5-chain ensembles of the reference's curve experiments not
 // even one wavefront for every SIMD).  The cooperative kernel of gsss_fast.h spreads a chain over 16 lanes but runs the
-// shrinkage loop one try after the other on nine of them.  Here a chain owns a GROUP of L = 4 (d <= 16) or 16 lanes:
+// shrinkage loop one try after the other on nine of them.  Here a chain owns a GROUP of L = 4 (d <= 64), 8 (d <= 128) or 16
+// lanes, each lane 4 Q of its components (gsss_fast_curvespec.hip has the measured choice of L and Q per dimension):
 //
 //  1. The O(d) work of a step -- normals, projection, the dots with the knots, the state update -- is spread over the
 //     group (CoopVec<L, 4 Q>: lane g holds the component quads g, g + L, ...; all sums are DPP reductions, after which

@@ -25,6 +25,15 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
         return do_curvespec<4, 4, 10>(tb, rb, replay, st);
     }
     if (tb.d <= 64) GSSS_SPEC(16, 1);
+    // d = 65 .. 128, <= 10 knots: eight-lane groups (1.5 / 1.3 against 1.0 for <16,2>)
+    if (tb.d <= 96 && tb.k <= 10) {
+        if (probe) GSSS_PROBE(lane, "curvespec_kernel<8, 3, 10>");
+        return do_curvespec<8, 3, 10>(tb, rb, replay, st);
+    }
+    if (tb.d <= 128 && tb.k <= 10) {
+        if (probe) GSSS_PROBE(lane, "curvespec_kernel<8, 4, 10>");
+        return do_curvespec<8, 4, 10>(tb, rb, replay, st);
+    }
     if (tb.d <= 128) GSSS_SPEC(16, 2);
     if (tb.d <= 192) GSSS_SPEC(16, 3);
     GSSS_SPEC(16, 4);
