@@ -170,23 +170,19 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 }
 
 // Box-Muller pair from two 32-bit words of a stream block: radius word -> (0,1], angle word -> [0,1)
+// (single precision inside, fm::box_muller_f32: the normals only give the tangent its direction; the same bits as the oracle's)
 __device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, double &z0, double &z1)
 {
-    const double r = sqrt(-2.0 * fm::log_fast(((double)wr + 1.0) * 0x1.0p-32));
-    double s, c;
-    fm::sincos_2pi((double)wa * 0x1.0p-32, s, c);
-    z0 = r * c;
-    z1 = r * s;
+    float f0, f1;
+    fm::box_muller_f32(wr, wa, f0, f1);
+    z0 = (double)f0;
+    z1 = (double)f1;
 }
 
 // the same pair with the table-driven log and sincos of gsss_math.h (throughput kernels; ~1 ulp from the above)
-__device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, const fm::Tables &t, double &z0, double &z1)
+__device__ __forceinline__ void box_muller32(uint32_t wr, uint32_t wa, const fm::Tables &, double &z0, double &z1)
 {
-    const double r = sqrt(-2.0 * fm::log_word_tab(wr, t));
-    double s, c;
-    fm::sincos_word_tab(wa, t, s, c);
-    z0 = r * c;
-    z1 = r * s;
+    box_muller32(wr, wa, z0, z1);
 }
 
 // Philox stream on S^2 (d = 3): the unit tangent u at x is drawn directly -- an angle phi in the tangent plane, ONE 32-bit

@@ -275,5 +275,72 @@ GSSS_HD double log_word_tab(uint32_t w, const Tables &t)
     return fma(dk, 6.93147180369123816490e-01, fma(dk, 1.90821492927058770002e-10, row[0] + l1p));
 }
 
+// ------------------------------------------------------------------------------------------
+// Box-Muller pair in SINGLE precision from two 32-bit words of the library stream (radius word: its upper 24 bits ->
+// (0, 1]; angle word -> [0, 1) revolutions).  The normals of a step only give the tangent its DIRECTION (mcmc.py:387, sphere.py:29-33): 24 bits
+// are plenty, and a pair costs ~50 two-cycle instructions instead of ~60 four-to-five-cycle ones.  Every operation is an
+// IEEE single-precision add, multiply, fma, square root or an exact integer / bit operation -- no hardware transcendental --
+// so the host (the oracle restates this function, gor_box_muller32) and the device produce the same bits.  Polynomials:
+// the classic single-precision minimax sets for log(1 + x) on [sqrt(1/2) - 1, sqrt(2) - 1] and sin / cos on [-pi/4, pi/4]
+// (Cephes), ~1e-7.
+// ------------------------------------------------------------------------------------------
+GSSS_HD uint32_t f32_bits(float x)
+{
+    uint32_t b;
+    __builtin_memcpy(&b, &x, sizeof(b));
+    return b;
+}
+GSSS_HD float bits_f32(uint32_t b)
+{
+    float x;
+    __builtin_memcpy(&x, &b, sizeof(x));
+    return x;
+}
+GSSS_HD void box_muller_f32(uint32_t wr, uint32_t wa, float &z0, float &z1)
+{
+    // ---- radius: sqrt(-2 ln v), v = ((wr >> 8) + 1) / 2^24 in (0, 1]: the upper 24 bits of the word, exact in single
+    // precision (the 2^-24 goes into the exponent count; radii up to 5.8)
+    const float vf = (float)((wr >> 8) + 1u);                // 1 .. 2^24
+    const uint32_t vb = f32_bits(vf);
+    int e = (int)(vb >> 23) - 127 - 24;                      // v = m 2^e, m in [1, 2)
+    float m = bits_f32((vb & 0x007FFFFFu) | 0x3F800000u);
+    const bool up = m > 1.41421356f;
+    m = up ? 0.5f * m : m;                                   // [sqrt(1/2), sqrt(2)]
+    e += up ? 1 : 0;
+    const float x = m - 1.0f;
+    const float z = x * x;
+    float p = fmaf(7.0376836292e-2f, x, -1.1514610310e-1f);
+    p = fmaf(p, x, 1.1676998740e-1f);
+    p = fmaf(p, x, -1.2420140846e-1f);
+    p = fmaf(p, x, 1.4249322787e-1f);
+    p = fmaf(p, x, -1.6668057665e-1f);
+    p = fmaf(p, x, 2.0000714765e-1f);
+    p = fmaf(p, x, -2.4999993993e-1f);
+    p = fmaf(p, x, 3.3333331174e-1f);
+    const float fe = (float)e;
+    float ln = fmaf(x * z, p, fe * -2.12194440e-4f);         // ln 2 = 0.693359375 - 2.12194440e-4
+    ln = fmaf(-0.5f, z, ln);
+    ln = (x + ln) + fe * 0.693359375f;
+    const float t = -2.0f * ln;
+    const float r = sqrtf(t > 0.0f ? t : 0.0f);
+    // ---- angle: 2 pi wa / 2^32 = k pi/4 + a, k = top three bits; reduced to the nearest multiple of pi/2
+    const uint32_t k = wa >> 29;
+    const float a = (float)(wa & 0x1FFFFFFFu) * 1.46291807926715968e-9f;   // pi/4 / 2^29
+    const float y = (k & 1u) ? a - 0.785398163397448f : a;                 // [-pi/4, pi/4]
+    const float yy = y * y;
+    float sp = fmaf(-1.9515295891e-4f, yy, 8.3321608736e-3f);
+    sp = fmaf(sp, yy, -1.6666654611e-1f);
+    const float sn = fmaf(y * yy, sp, y);
+    float cp = fmaf(2.443315711809948e-5f, yy, -1.388731625493765e-3f);
+    cp = fmaf(cp, yy, 4.166664568298827e-2f);
+    const float cs = fmaf(yy * yy, cp, fmaf(-0.5f, yy, 1.0f));
+    const uint32_t q = ((k + 1u) >> 1) & 3u;                 // quarter turns
+    const float c0 = (q & 1u) ? sn : cs, s0 = (q & 1u) ? cs : sn;
+    const float c = (q == 1u || q == 2u) ? -c0 : c0;
+    const float sg = (q >= 2u) ? -s0 : s0;
+    z0 = r * c;
+    z1 = r * sg;
+}
+
 }  // namespace fm
 }  // namespace gsss

@@ -123,7 +123,7 @@ typedef struct gsss_target_desc {
  * step s are a pure function of (seed, chain_offset + c, step_offset + s), so any split of
  * the chains over devices or of the steps over calls reproduces the same numbers
  * (DESIGN.md §3 "Random streams").  On this stream a step draws d normals for the tangent direction as the reference does
- * (mcmc.py:387) -- except on S^2 (d = 3), where the uniformly distributed unit tangent is drawn directly as one angle in
+ * (mcmc.py:387; Box-Muller pairs formed in single precision: they only set a direction) -- except on S^2 (d = 3), where the uniformly distributed unit tangent is drawn directly as one angle in
  * the tangent plane and one block carries the whole set-up of a step (same law; the two sources below keep the reference's
  * normals and draw order).
  * If replay_dev is non-NULL the draws are read from it instead:

@@ -385,12 +385,68 @@ void gor_stream_block(uint64_t seed, uint64_t chain, uint64_t step, uint32_t blk
 }
 
 /* ... or as two Box-Muller pairs from four 32-bit uniforms (radius word in (0,1], angle word in [0,1)) */
+/* In SINGLE precision, operation for operation fm::box_muller_f32 of geosss_amd/csrc/gsss_math.h (IEEE add, multiply, fma,
+ * square root and exact bit operations only, so host and device agree to the bit): the normals only give the tangent its
+ * direction (mcmc.py:387, sphere.py:29-33), 24 bits are plenty.  Polynomials: the classic single-precision minimax sets for
+ * log(1 + x) and sin / cos on [-pi/4, pi/4] (Cephes). */
+static uint32_t gor_f32_bits(float x)
+{
+    uint32_t b;
+    memcpy(&b, &x, sizeof(b));
+    return b;
+}
+static float gor_bits_f32(uint32_t b)
+{
+    float x;
+    memcpy(&x, &b, sizeof(x));
+    return x;
+}
 static void gor_box_muller32(uint32_t wr, uint32_t wa, double *z0, double *z1)
 {
-    double r = sqrt(-2.0 * log(((double)wr + 1.0) * (1.0 / 4294967296.0)));
-    double ang = 6.283185307179586 * ((double)wa * (1.0 / 4294967296.0));
-    *z0 = r * cos(ang);
-    *z1 = r * sin(ang);
+    const float vf = (float)((wr >> 8) + 1u);
+    const uint32_t vb = gor_f32_bits(vf);
+    int e = (int)(vb >> 23) - 127 - 24;
+    float m = gor_bits_f32((vb & 0x007FFFFFu) | 0x3F800000u);
+    const int up = m > 1.41421356f;
+    m = up ? 0.5f * m : m;
+    e += up ? 1 : 0;
+    const float x = m - 1.0f;
+    const float z = x * x;
+    float p = fmaf(7.0376836292e-2f, x, -1.1514610310e-1f);
+    p = fmaf(p, x, 1.1676998740e-1f);
+    p = fmaf(p, x, -1.2420140846e-1f);
+    p = fmaf(p, x, 1.4249322787e-1f);
+    p = fmaf(p, x, -1.6668057665e-1f);
+    p = fmaf(p, x, 2.0000714765e-1f);
+    p = fmaf(p, x, -2.4999993993e-1f);
+    p = fmaf(p, x, 3.3333331174e-1f);
+    const float fe = (float)e;
+    float ln = fmaf(x * z, p, fe * -2.12194440e-4f);
+    ln = fmaf(-0.5f, z, ln);
+    ln = (x + ln) + fe * 0.693359375f;
+    const float t = -2.0f * ln;
+    const float r = sqrtf(t > 0.0f ? t : 0.0f);
+    const uint32_t k = wa >> 29;
+    const float a = (float)(wa & 0x1FFFFFFFu) * 1.46291807926715968e-9f;
+    const float y = (k & 1u) ? a - 0.785398163397448f : a;
+    const float yy = y * y;
+    float sp = fmaf(-1.9515295891e-4f, yy, 8.3321608736e-3f);
+    sp = fmaf(sp, yy, -1.6666654611e-1f);
+    const float sn = fmaf(y * yy, sp, y);
+    float cp = fmaf(2.443315711809948e-5f, yy, -1.388731625493765e-3f);
+    cp = fmaf(cp, yy, 4.166664568298827e-2f);
+    const float cs = fmaf(yy * yy, cp, fmaf(-0.5f, yy, 1.0f));
+    const uint32_t q = ((k + 1u) >> 1) & 3u;
+    const float c0 = (q & 1u) ? sn : cs, s0 = (q & 1u) ? cs : sn;
+    const float c = (q == 1u || q == 2u) ? -c0 : c0;
+    const float sg = (q >= 2u) ? -s0 : s0;
+    *z0 = (double)(r * c);
+    *z1 = (double)(r * sg);
+}
+/* exposed for tests/test_math.py: the oracle's pair against the host build of gsss_math.h, bit for bit */
+void gor_box_muller32_fill(const uint32_t *wr, const uint32_t *wa, int64_t n, double *z0, double *z1)
+{
+    for (int64_t i = 0; i < n; ++i) gor_box_muller32(wr[i], wa[i], z0 + i, z1 + i);
 }
 
 /* ---- numpy's PCG64 (XSL-RR 128/64, setseq) and the distributions built on it ---- */

@@ -23,3 +23,13 @@ void t_sincos_tab(const double *x, long n, double *s, double *c) { auto t = host
 void t_sincos_word_tab(const unsigned *w, long n, double *s, double *c) { auto t = host_tables(); for (long i = 0; i < n; ++i) gsss::fm::sincos_word_tab(w[i], t, s[i], c[i]); }
 void t_log_word_tab(const unsigned *w, long n, double *y) { auto t = host_tables(); for (long i = 0; i < n; ++i) y[i] = gsss::fm::log_word_tab(w[i], t); }
 }
+
+extern "C" void t_box_muller_f32(const unsigned *wr, const unsigned *wa, long n, double *z0, double *z1)
+{
+    for (long i = 0; i < n; ++i) {
+        float a, b;
+        gsss::fm::box_muller_f32(wr[i], wa[i], a, b);
+        z0[i] = a;
+        z1[i] = b;
+    }
+}

@@ -123,3 +123,27 @@ def test_table_driven_functions(lib):
     nz = want != 0
     assert np.max(np.abs(y[nz] - want[nz]) / np.abs(want[nz])) < 1e-15
     assert y[-1] == 0.0                                                                     # w = 2^32 - 1 -> log 1
+
+
+def test_single_precision_box_muller_host_oracle_bit_identical(lib):
+    """fm::box_muller_f32 (gsss_math.h, what the kernels run) and the oracle's restatement gor_box_muller32 are the same
+    IEEE single-precision operations: identical bits on 2 million word pairs incl. the corners; and the pair is the
+    Box-Muller transform to single precision (radius and angle against libm in double)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(9)
+    n = 2_000_000
+    wr = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    wa = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    corners = np.array([0, 1, 2, 2**23, 2**24 - 1, 2**24, 2**29 - 1, 2**29, 2**31, 2**32 - 2, 2**32 - 1], dtype=np.uint32)
+    wr[:len(corners)] = corners
+    wa[len(corners):2 * len(corners)] = corners
+    a0, a1 = np.empty(n), np.empty(n)
+    lib.t_box_muller_f32(_p(wr), _p(wa), C.c_long(n), _p(a0), _p(a1))
+    b0, b1 = np.empty(n), np.empty(n)
+    orc.lib().gor_box_muller32_fill(_p(wr), _p(wa), C.c_int64(n), _p(b0), _p(b1))
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+    r = np.sqrt(-2.0 * np.log(((wr >> 8).astype(np.float64) + 1.0) / 2.0**24))
+    ang = 2.0 * np.pi * wa.astype(np.float64) / 2.0**32
+    assert np.max(np.abs(a0 - r * np.cos(ang))) < 4e-6 and np.max(np.abs(a1 - r * np.sin(ang))) < 4e-6
+    assert np.max(np.abs(np.hypot(a0, a1) - r) / np.maximum(r, 1e-3)) < 1e-6
+    assert abs(a0.mean()) < 3e-3 and abs(a0.var() - 1) < 5e-3 and abs(np.mean(a0 * a1)) < 3e-3
