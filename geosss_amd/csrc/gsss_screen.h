@@ -216,16 +216,23 @@ struct ScreenBingham : FastBingham<D> {
     }
     __device__ __forceinline__ bool make32(const Coef &cf, double u_thr, float (&q)[kCoef32Floats]) const
     {
+        // thr = level(x) + log U (mcmc.py:389), log U in single precision: the screen needs the threshold to ~1e-6 of the
+        // coefficients' scale, and the error of the logarithm (log2_32: <= kLog2Err32 + 2^-24 |log2 U|, times ln 2, one
+        // more rounding each for the product and the two differences) goes into the margin; the double-precision
+        // threshold is formed when a try stays undecided (threshold())
         const double lvl0 = cf.qxx + cf.bx;
-        const double thr = lvl0 + fm::log_fast(u_thr);  // mcmc.py:389
-        q[0] = (float)(cf.qxx - thr);
+        const float l2 = log2_32(u_thr);
+        const float lu = l2 * 0.69314718f;
+        q[0] = (float)(cf.qxx - lvl0) - lu;
         q[1] = (float)cf.qxu;
-        q[2] = (float)(cf.quu - thr);
+        q[2] = (float)(cf.quu - lvl0) - lu;
         q[3] = (float)cf.bx;
         q[4] = (float)cf.bu;
         const float sum = fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]) + fabsf(q[3]) + fabsf(q[4]);
-        // every term carries at most two trigonometric factors (2 eps), its coefficient's rounding and the fma roundings
-        float margin = 1.25f * sum * (2.0f * kSinCosErr32 + 6.0f * kUnit32) + 1.0e-30f;
+        const float e_lu = (kLog2Err32 + 2.0f * kUnit32 * fabsf(l2)) * 0.6932f + kUnit32 * (fabsf(lu) + fabsf(q[0]) + fabsf(q[2]));
+        // every term carries at most two trigonometric factors (2 eps), its coefficient's rounding and the fma roundings;
+        // the threshold's error enters through c^2 q0 + s^2 q2 with weight c^2 + s^2 = 1
+        float margin = 1.25f * (sum * (2.0f * kSinCosErr32 + 6.0f * kUnit32) + e_lu) + 1.0e-30f;
         if (!(u_thr > 1e-290) || !(margin < 1.0e30f)) margin = INFINITY;
         q[5] = margin;
         return lvl0 > -INFINITY && lvl0 < INFINITY;
