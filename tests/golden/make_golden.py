@@ -197,8 +197,11 @@ def cases():
     bf6 = gs.BinghamFisher(np.diag([-1000.0, -600.0, -200.0, 200.0, 600.0, 1000.0]),
                            np.array([100.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
     out["binghamfisher_d6"] = (bf6, gs.sphere.sample_sphere(5, seed=8), 84, 300)
+    # d = 17, 40, 100, 160: one chain for every lane-group shape of the group-speculative curve kernel
+    # (gsss_fast_curvespec.hip: <4,2>, <4,3>, <8,4>, <16,3>) next to the BASELINE dimensions
     for d, kappa, n in ((3, 300.0, 300), (10, 800.0, 300), (10, 500.0, 200), (24, 800.0, 150),
-                        (50, 800.0, 150), (200, 800.0, 100)):
+                        (50, 800.0, 150), (200, 800.0, 100), (17, 800.0, 120), (40, 800.0, 100), (100, 800.0, 80),
+                        (160, 800.0, 60)):
         out[f"curve_d{d}_kappa{int(kappa)}"] = (
             curve_target(d, kappa), gs.sphere.sample_sphere(d - 1, seed=1345), 90 + d, n)
     return out
