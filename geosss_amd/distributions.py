@@ -19,7 +19,7 @@ import ctypes as C
 
 import numpy as np
 import torch
-from scipy.special import i0, ive
+from scipy.special import i0, ive, iv, logsumexp
 
 from . import _lib
 from .sphere import _device_index, current_stream_ptr
@@ -186,6 +186,69 @@ class VonMisesFisher(Distribution):
         return self.mu
 
 
+class _HostDensity(Distribution):
+    """Densities the reference defines beside its sampler targets (plot overlays, envelopes): evaluated on the host with
+    numpy, as the reference does; they have no device parameter block and are refused as targets of the HIP samplers."""
+
+    def _pack(self):
+        raise TypeError(f"{type(self).__name__} is a host-side density (plotting / envelope); the HIP samplers run on "
+                        "VonMisesFisher, MixtureModel, Bingham, BinghamFisher, CurvedVonMisesFisher, Uniform and the "
+                        "registration targets")
+
+
+class MarginalVonMisesFisher(_HostDensity, VonMisesFisher):
+    """The density on [-1, 1] of coordinate `dim_idx` of a vMF(mu) variate (distributions.py:164-186): what the
+    reference's diagnostics overlay on the histograms of the chains' coordinates."""
+
+    def __init__(self, dim_idx, mu):
+        VonMisesFisher.__init__(self, mu)
+        self.dim_idx = dim_idx
+
+    def prob(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        d, kappa = self.d, self.kappa
+        m = self.mu[self.dim_idx] / kappa                        # the mean direction's own coordinate
+        rest = (1.0 - m * m) * (1.0 - x * x)
+        return (np.sqrt(kappa / (2.0 * np.pi)) / iv(0.5 * d - 1.0, kappa) * ((1.0 - x * x) / (1.0 - m * m)) ** (0.25 * (d - 3))
+                * np.exp(kappa * m * x) * iv(0.5 * (d - 3), kappa * np.sqrt(rest)))
+
+    @counted
+    def log_prob(self, x):
+        return np.log(np.clip(self.prob(x), 1e-308, None))
+
+
+class MultivariateNormal(_HostDensity):
+    """-(x - mu)^T C^-1 (x - mu) / 2 (distributions.py:189-197)."""
+
+    def __init__(self, mu, C):
+        self.mu = np.asarray(mu, dtype=np.float64)
+        self.C = np.asarray(C, dtype=np.float64)
+        self.invC = np.linalg.inv(self.C)
+
+    @property
+    def d(self):
+        return len(self.C)
+
+    def _quad(self, x):
+        r = np.asarray(x, dtype=np.float64) - self.mu
+        return np.sum(r * (r @ self.invC), axis=-1)
+
+    @counted
+    def log_prob(self, x):
+        return -0.5 * self._quad(x)
+
+
+class ACG(MultivariateNormal):
+    """Angular central Gaussian: -(d / 2) log(x^T C^-1 x) (distributions.py:200-207); the envelope of rand.sample_bingham."""
+
+    def __init__(self, C):
+        super().__init__(np.zeros(len(C)), C)
+
+    @counted
+    def log_prob(self, x):
+        return -0.5 * self.d * np.log(self._quad(x))
+
+
 class MixtureModel(Distribution):
     """log_prob = logsumexp_k(log_prob_k(x) + log w_k), weights normalised to one
     (distributions.py:211-221).  Components must be VonMisesFisher of one dimension."""
@@ -194,6 +257,11 @@ class MixtureModel(Distribution):
         self.pdfs = list(components)
         if not self.pdfs or not all(isinstance(p, VonMisesFisher) for p in self.pdfs):
             raise TypeError("the HIP path covers mixtures of VonMisesFisher components")
+        # a mixture of coordinate marginals (the reference's histogram overlay, scripts/vMF_diagnostics.py:106-108) is a
+        # density on [-1, 1]: host arithmetic, never a sampler target
+        self._marginal = all(isinstance(p, MarginalVonMisesFisher) for p in self.pdfs)
+        if not self._marginal and any(isinstance(p, MarginalVonMisesFisher) for p in self.pdfs):
+            raise TypeError("cannot mix coordinate marginals with densities on the sphere")
         if len({p.d for p in self.pdfs}) != 1:
             raise ValueError("all components must share the dimension")
         w = np.ones(len(self.pdfs)) if weights is None else np.array(weights, dtype=np.float64)
@@ -206,6 +274,8 @@ class MixtureModel(Distribution):
         return self.pdfs[0].d
 
     def _pack(self):
+        if self._marginal:
+            return _HostDensity._pack(self)
         mu = _as_f64([p.mu for p in self.pdfs])
         with np.errstate(divide="ignore"):
             logw = np.log(self.weights)
@@ -214,6 +284,9 @@ class MixtureModel(Distribution):
 
     @counted
     def log_prob(self, x):
+        if self._marginal:
+            with np.errstate(divide="ignore"):
+                return logsumexp(np.stack([p.log_prob(x) for p in self.pdfs], axis=-1) + np.log(self.weights), axis=-1)
         return self._log_prob_device(x)
 
 
@@ -272,6 +345,32 @@ class BinghamFisher(Bingham):
         return 2 * self.A @ x + self.b
 
 
+class Uniform(Bingham):
+    """The uniform distribution on the sphere (distributions.py:28-34): log_prob = 0.  The reference's class carries no
+    dimension; to run a sampler on it give the ambient dimension, Uniform(d) -- on the device it is the Bingham target
+    with A = 0."""
+
+    def __init__(self, d=None):
+        self._d = None if d is None else int(d)
+        if d is not None:
+            super().__init__(np.zeros((self._d, self._d)))
+
+    @property
+    def d(self):
+        return self._d
+
+    def _pack(self):
+        if self._d is None:
+            raise TypeError("Uniform() has no dimension: construct it as Uniform(d) to sample it on the device")
+        return super()._pack()
+
+    def log_prob(self, x):
+        return 0.0
+
+    def gradient(self, x):
+        return np.zeros_like(x)
+
+
 def random_bingham(d=2, vmax=None, vmin=None, eigensystem=False, seed=None):
     """Random Bingham target with the construction of distributions.py:230-258, so that the same
     seed gives the same precision matrix as the reference (e.g. scripts/bingham.py:131 uses
@@ -295,6 +394,43 @@ class SlerpCurve:
         self.knots = np.array(knots, dtype=np.float64)
         if self.knots.ndim != 2 or self.knots.shape[0] < 2:
             raise ValueError("need at least two knots")
+        # arc lengths and the normalised arc-length parameter of the knots (spherical_curve.py:80-85)
+        seg = np.arccos(np.clip(np.sum(self.knots[:-1] * self.knots[1:], axis=-1), -1, 1))
+        self.theta = np.append(0.0, seg)
+        self.bins = np.cumsum(self.theta) / np.sum(self.theta)
+        self.widths = np.diff(self.bins)
+
+    def __call__(self, t):
+        """Points of the curve at arc-length parameters t in [0, 1] (spherical_curve.py:87-93) -- for plots; the sampler
+        kernels never evaluate the curve, they project onto it."""
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        s = self.bins
+        i = np.clip(np.digitize(t, s, right=True), 1, len(self.knots) - 1)
+        omega, span = self.theta[i], s[i] - s[i - 1]
+        wa = np.sin(omega * (s[i] - t) / span) / np.sin(omega)
+        wb = np.sin(omega * (t - s[i - 1]) / span) / np.sin(omega)
+        return wa[:, None] * self.knots[i - 1] + wb[:, None] * self.knots[i]
+
+    def find_nearest(self, point):
+        """The point of the curve closest to `point` (spherical_curve.py:95-102): per segment the clipped great-arc
+        projection of distance_slerp, then the first segment of least distance.  Host helper for plots and checks; on
+        the sampler's path the projection lives in the kernels (CurvedVonMisesFisher.log_prob evaluates there)."""
+        best, out = np.inf, None
+        for a, b in zip(self.knots[:-1], self.knots[1:]):
+            dist, y = distance_slerp(point, a, b)
+            if dist < best:
+                best, out = dist, y
+        return out
+
+
+def distance_slerp(x, a, b):
+    """(geodesic distance from `x` to the great arc a -> b, closest point of the arc) (spherical_curve.py:10-32)."""
+    x, a, b = (np.asarray(v, dtype=np.float64) for v in (x, a, b))
+    arc = np.arccos(np.clip(a @ b, -1, 1))
+    ax, bx = a @ x, b @ x
+    t = np.clip(np.arctan2(bx - ax * np.cos(arc), ax * np.sin(arc)), 0.0, arc)
+    y = (np.sin(arc - t) * a + np.sin(t) * b) / (np.sin(arc) + 1e-10)
+    return np.arccos(np.clip(x @ y, -1, 1)), y
 
 
 def brownian_curve(n_points=100, dimension=6, step_size=0.05, seed=1234):
@@ -307,6 +443,31 @@ def brownian_curve(n_points=100, dimension=6, step_size=0.05, seed=1234):
     for i in range(1, n_points):
         w = pts[i - 1] + g.normal(size=dimension) * step_size
         pts[i] = w / (np.linalg.norm(w) + 1e-100)
+    return pts
+
+
+def constrained_brownian_curve(n_points=100, dimension=6, step_size=0.05, seed=1234):
+    """Knots of a smooth walk on the sphere that keeps its heading (spherical_curve.py:132-181; the curve of
+    scripts/curve_3d.py): each step turns the unit heading by `step_size` towards a random direction orthogonal to both the
+    position and the heading, re-tangentialises it, and moves the point by the angle `step_size` along it.  Same seed ->
+    same knots as the reference."""
+    g = np.random.default_rng(seed)
+    pts = np.zeros((n_points, dimension))
+    z = g.standard_normal(dimension)
+    pts[0] = z / (np.linalg.norm(z) + 1e-100)
+
+    def tangential_unit(w, p):
+        w = w - (w @ p) * p
+        return w / np.linalg.norm(w)
+
+    heading = tangential_unit(g.standard_normal(dimension), pts[0])
+    for i in range(1, n_points):
+        p = pts[i - 1]
+        kick = g.standard_normal(dimension)
+        kick -= (kick @ p) * p
+        kick -= (kick @ heading) * heading
+        heading = tangential_unit(heading + step_size * kick / np.linalg.norm(kick), p)
+        pts[i] = np.cos(step_size) * p + np.sin(step_size) * heading
     return pts
 
 

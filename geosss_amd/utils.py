@@ -9,6 +9,34 @@ from .mcmc import MetropolisHastings, RejectionSphericalSliceSampler, ShrinkageS
 
 count_calls = counted
 
+# the reference's plot palette and overflow-safe elementary functions (utils.py:15-88), for scripts that import them
+colors = [(0.85, 0.3, 0.1), (0.15, 0.35, 0.6), (0.95, 0.7, 0.1), (0.0, 0.0, 0.0), (0.8, 0.8, 0.8)]
+EXP_MIN, EXP_MAX = -308, 709
+LOG_MIN, LOG_MAX = 1e-308, 1e308
+
+
+def format_time(t):
+    """Seconds -> "12.3 ms" (utils.py:31-37)."""
+    scale, unit = next(((s, u) for s, u in ((1.0, "s"), (1e-3, "ms"), (1e-6, "us"), (1e-9, "ns")) if t > s or t == 0), (1e-9, "ns"))
+    return "%.1f %s" % (t / scale, unit)
+
+
+def exp(x, x_min=EXP_MIN, x_max=EXP_MAX):
+    """exp of the argument clipped into [max(x_min, -308), min(x_max, 709)]: never overflows (utils.py:49-67)."""
+    import numpy as np
+    return np.exp(np.clip(x, max(x_min, EXP_MIN), min(x_max, EXP_MAX)))
+
+
+def log(x, x_min=LOG_MIN, x_max=LOG_MAX):
+    """log of the argument clipped into [max(x_min, 1e-308), min(x_max, 1e308)] (utils.py:70-83)."""
+    import numpy as np
+    return np.log(np.clip(x, max(x_min, LOG_MIN), min(x_max, LOG_MAX)))
+
+
+def relative_entropy(p, q):
+    """Kullback-Leibler divergence sum_i p_i (log p_i - log q_i) with the clipped log (utils.py:86-88)."""
+    return p @ (log(p) - log(q))
+
 
 @contextlib.contextmanager
 def take_time(desc, mute=False):
@@ -24,8 +52,7 @@ def take_time(desc, mute=False):
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if not mute:
-        scale, unit = next(((s, u) for s, u in ((1.0, "s"), (1e-3, "ms"), (1e-6, "us"), (1e-9, "ns")) if dt > s or dt == 0), (1e-9, "ns"))
-        logging.info("%s took %.1f %s", desc, dt / scale, unit)
+        logging.info("%s took %s", desc, format_time(dt))
 
 
 def counter(method_names):

@@ -520,8 +520,92 @@ def make_cpd():
         save(f"mh_hmc_{name}.npz", x0=x0, grad_X=GX, grad=grad, **flat_params(target_params(pdf)), **hm)
 
 
+def make_helpers():
+    """Known answers of the reference's helper functions either side of the sampler: geosss/sphere.py coordinate maps,
+    great-circle interpolation / rotation, sample_subsphere / sample_marginal, the host-side densities of
+    geosss/distributions.py (marginal vMF, multivariate normal, ACG) and the clipped elementary functions of utils.py."""
+    from geosss import utils as rutils
+    from geosss.distributions import ACG, MarginalVonMisesFisher, MixtureModel, MultivariateNormal
+    rng = np.random.default_rng(20250607)
+    a = {}
+    X3 = rsphere.sample_sphere(2, 32, seed=11)
+    a["X3"] = X3
+    a["polar"] = rsphere.cartesian2polar(X3)
+    a["sph_phi"], a["sph_theta"] = rsphere.cartesian2spherical(X3)
+    a["angles"] = rng.uniform(0, 2 * np.pi, 16)
+    a["polar2cart"] = rsphere.polar2cartesian(a["angles"])
+    a["theta"] = rng.uniform(0, np.pi, 16)
+    a["sph2cart"] = rsphere.spherical2cartesian(a["angles"], a["theta"])
+    for d in (4, 10):
+        v = rsphere.sample_sphere(d - 1, seed=7 + d)
+        a[f"d{d}_pole"] = v
+        a[f"d{d}_subsphere"] = rsphere.sample_subsphere(v, seed=3)
+        a[f"d{d}_marginal"] = rsphere.sample_marginal(d, size=8, seed=5)
+        u = rsphere.sample_subsphere(v, seed=9)
+        x = rsphere.sample_sphere(d - 1, seed=21 + d)
+        a[f"d{d}_u"], a[f"d{d}_x"] = u, x
+        tangent = 0.7 * rng.standard_normal(d)
+        a[f"d{d}_tangent"] = tangent
+        a[f"d{d}_wrap"] = rsphere.wrap(tangent, u, v)
+        phis = rng.uniform(0, 1.2, 6)
+        a[f"d{d}_phis"] = phis
+        a[f"d{d}_slerp"] = np.array([rsphere.slerp(v, x)(p) for p in phis])
+        a[f"d{d}_givens"] = np.array([rsphere.givens(u, v, x)(p) for p in phis])
+        a[f"d{d}_distance"] = rsphere.distance(np.stack([u, v, x]), np.stack([x, x, x]))
+    grid = np.linspace(-0.999, 0.999, 41)
+    a["grid"] = grid
+    for d, kappa in ((3, 80.0), (10, 100.0)):
+        mus = kappa * rsphere.sample_sphere(d - 1, 3, seed=1234)
+        a[f"marg_d{d}_mus"] = mus
+        a[f"marg_d{d}_prob"] = np.array([[MarginalVonMisesFisher(i, mu).prob(grid) for i in range(d)] for mu in mus])
+        a[f"marg_d{d}_log_prob"] = np.array([[MarginalVonMisesFisher(i, mu).log_prob(grid) for i in range(d)] for mu in mus])
+        a[f"marg_d{d}_mixture"] = np.array([MixtureModel([MarginalVonMisesFisher(i, mu) for mu in mus]).log_prob(grid)
+                                            for i in range(d)])
+    M = rng.standard_normal((5, 5))
+    C = M @ M.T + 5 * np.eye(5)
+    mu = rng.standard_normal(5)
+    Y = rng.standard_normal((12, 5))
+    a["mvn_C"], a["mvn_mu"], a["mvn_Y"] = C, mu, Y
+    # the reference leaves `gradient` abstract on these two, so they cannot be instantiated as they stand: close them
+    concrete = lambda cls: type(cls.__name__, (cls,), {"gradient": lambda self, x: None})
+    a["mvn_log_prob"] = concrete(MultivariateNormal)(mu, C).log_prob(Y)
+    a["acg_log_prob"] = concrete(ACG)(C).log_prob(Y)
+    z = np.array([-1e4, -308.5, -1.0, 0.0, 1.0, 709.5, 1e4])
+    a["clip_in"] = z
+    a["clip_exp"] = rutils.exp(z)
+    w = np.array([0.0, 1e-320, 1e-308, 1.0, 1e308, np.inf])
+    a["clip_log_in"] = w
+    a["clip_log"] = rutils.log(w)
+    p = rng.dirichlet(np.ones(8))
+    q = rng.dirichlet(np.ones(8))
+    q[2] = 0.0
+    a["kl_p"], a["kl_q"], a["kl"] = p, q, np.float64(rutils.relative_entropy(p, q))
+    a["format_time"] = np.array([rutils.format_time(t) for t in (0.0, 3.2, 0.0123, 4.5e-5, 7e-8, 2e-11)])
+    a["format_time_in"] = np.array([0.0, 3.2, 0.0123, 4.5e-5, 7e-8, 2e-11])
+    from geosss.spherical_curve import constrained_brownian_curve
+    for d in (3, 7):
+        knots = constrained_brownian_curve(n_points=12, dimension=d, step_size=0.3, seed=77 + d)
+        curve = SlerpCurve(knots)
+        a[f"cbc_d{d}_knots"] = knots
+        a[f"cbc_d{d}_theta"], a[f"cbc_d{d}_bins"], a[f"cbc_d{d}_widths"] = curve.theta, curve.bins, curve.widths
+        ts = np.concatenate([[0.0, 1.0], rng.uniform(0, 1, 14), curve.bins[3:5]])
+        a[f"cbc_d{d}_t"] = ts
+        a[f"cbc_d{d}_points"] = curve(ts)
+    # result files as the reference's scripts write them (geosss/io.py: pickle protocol 2, plain and gzip)
+    from geosss.io import dump
+    runs = {m: rng.standard_normal((3, 5, 4)) for m in ("sss-reject", "sss-shrink", "rwmh", "hmc")}
+    here = os.path.dirname(os.path.abspath(__file__))
+    dump(runs, os.path.join(here, "ref_dump.pkl"))
+    dump({"ess": [runs["rwmh"][0], 3.5, "text"], "n": 7}, os.path.join(here, "ref_dump.pkl.gz"), gzip=True)
+    for m, v in runs.items():
+        a["dump_" + m] = v
+    save("helpers_kat.npz", **a)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh", "mhk", "cpd"]
+    what = sys.argv[1:] or ["traj", "logprob", "geometry", "stats", "timing", "diagnostics", "mh", "mhk", "cpd", "helpers"]
+    if "helpers" in what:
+        make_helpers()
     if "mhk" in what:
         make_mh_kernels()
     if "cpd" in what:

@@ -1,0 +1,194 @@
+"""The reference's helper functions either side of the sampler (geosss/sphere.py coordinate maps and great-circle
+helpers, the host-side densities of geosss/distributions.py, the clipped elementary functions of geosss/utils.py) against
+values the reference itself produced (tests/golden/helpers_kat.npz, written by make_golden.py `helpers`)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+TOL = dict(rtol=0, atol=1e-13)
+
+
+def _sphere_checks(to, back):
+    """`to`: numpy -> the container under test; `back`: its result -> numpy"""
+    from geosss_amd import sphere as S
+    z = golden("helpers_kat.npz")
+    X3 = to(z["X3"])
+    assert np.allclose(back(S.cartesian2polar(X3)), z["polar"], **TOL)
+    phi, theta = S.cartesian2spherical(X3)
+    assert np.allclose(back(phi), z["sph_phi"], **TOL) and np.allclose(back(theta), z["sph_theta"], **TOL)
+    assert np.allclose(back(S.polar2cartesian(to(z["angles"]))), z["polar2cart"], **TOL)
+    assert np.allclose(back(S.spherical2cartesian(to(z["angles"]), to(z["theta"]))), z["sph2cart"], **TOL)
+    for d in (4, 10):
+        v, u, x = to(z[f"d{d}_pole"]), to(z[f"d{d}_u"]), to(z[f"d{d}_x"])
+        assert np.allclose(back(S.sample_subsphere(v, seed=3)), z[f"d{d}_subsphere"], **TOL)
+        assert np.allclose(back(S.wrap(to(z[f"d{d}_tangent"]), u, v)), z[f"d{d}_wrap"], **TOL)
+        arc, rot = S.slerp(v, x), S.givens(u, v, x)
+        for i, p in enumerate(z[f"d{d}_phis"]):
+            assert np.allclose(back(arc(float(p))), z[f"d{d}_slerp"][i], **TOL)
+            assert np.allclose(back(rot(float(p))), z[f"d{d}_givens"][i], **TOL)
+        stack = (torch.stack if isinstance(v, torch.Tensor) else np.stack)
+        got = S.distance(stack([u, v, x]), stack([x, x, x]))
+        # arccos at 1 turns the last-bit difference of two summation orders into ~1e-8 for the (x, x) pair
+        assert np.allclose(back(got)[:2], z[f"d{d}_distance"][:2], **TOL) and abs(back(got)[2]) < 1e-7
+    # the projections: batch and single point, non-unit poles (the fixtures of the geometry KAT)
+    g = golden("geometry_kat.npz")
+    for d in (3, 10, 50):
+        X, Z = g[f"d{d}_x"], g[f"d{d}_z"]
+        assert np.allclose(back(S.radial_projection(to(X))), g[f"d{d}_radial"], **TOL)
+        assert np.allclose(back(S.radial_projection(to(X[0]))), g[f"d{d}_radial"][0], **TOL)
+        for i in range(4):
+            assert np.allclose(back(S.orthogonal_projection(to(Z[i]), to(X[i]))), g[f"d{d}_ortho"][i], **TOL)
+            assert np.allclose(back(S.spherical_projection(to(Z[i]), to(X[i]))), g[f"d{d}_spherical"][i], **TOL)
+        many = S.spherical_projection(to(Z), to(X[0]))                # a batch against one pole
+        assert many.shape == Z.shape and np.allclose(back(many)[0], g[f"d{d}_spherical"][0], **TOL)
+        assert np.max(np.abs(back(many) @ X[0])) < 1e-12
+
+
+def test_sphere_helpers_numpy():
+    from geosss_amd import sphere as S
+    _sphere_checks(lambda a: np.array(a), lambda a: np.asarray(a))
+    z = golden("helpers_kat.npz")
+    for d in (4, 10):
+        assert np.array_equal(S.sample_marginal(d, size=8, seed=5), z[f"d{d}_marginal"])
+    assert isinstance(S.radial_projection(np.array([3.0, 4.0])), np.ndarray)
+
+
+def test_sphere_helpers_torch_cpu():
+    _sphere_checks(lambda a: torch.as_tensor(np.array(a)), lambda a: a.numpy())
+
+
+@pytest.mark.gpu
+def test_sphere_helpers_device_tensors():
+    out = []
+    _sphere_checks(lambda a: torch.as_tensor(np.array(a)).cuda(), lambda a: (out.append(a.is_cuda), a.cpu().numpy())[1])
+    assert all(out)                                                  # results stayed on the device
+
+
+def test_host_densities_against_reference_values():
+    """MarginalVonMisesFisher (and the mixture of marginals the reference's diagnostics plot over the coordinate
+    histograms, scripts/vMF_diagnostics.py:106-108), MultivariateNormal, ACG, Uniform."""
+    import geosss_amd as gs
+    z = golden("helpers_kat.npz")
+    grid = z["grid"]
+    for d in (3, 10):
+        mus = z[f"marg_d{d}_mus"]
+        for k, mu in enumerate(mus):
+            for i in range(d):
+                m = gs.MarginalVonMisesFisher(i, mu)
+                assert np.allclose(m.prob(grid), z[f"marg_d{d}_prob"][k, i], rtol=1e-12, atol=0)
+                assert np.allclose(m.log_prob(grid), z[f"marg_d{d}_log_prob"][k, i], rtol=1e-12, atol=1e-12)
+        for i in range(d):
+            mix = gs.MixtureModel([gs.MarginalVonMisesFisher(i, mu) for mu in mus])
+            assert np.allclose(mix.log_prob(grid), z[f"marg_d{d}_mixture"][i], rtol=1e-12, atol=1e-12)
+        # a density on [-1, 1]: integrates to one, and is no target for the samplers
+        fine = np.linspace(-1, 1, 20001)[1:-1]
+        assert abs(np.trapezoid(gs.MarginalVonMisesFisher(0, mus[0]).prob(fine), fine) - 1.0) < 1e-3
+        with pytest.raises(TypeError):
+            gs.MarginalVonMisesFisher(0, mus[0])._pack()
+        with pytest.raises(TypeError):
+            gs.MixtureModel([gs.MarginalVonMisesFisher(0, mu) for mu in mus])._pack()
+        with pytest.raises(TypeError):
+            gs.MixtureModel([gs.MarginalVonMisesFisher(0, mus[0]), gs.VonMisesFisher(mus[1])])
+    mvn = gs.MultivariateNormal(z["mvn_mu"], z["mvn_C"])
+    assert np.allclose(mvn.log_prob(z["mvn_Y"]), z["mvn_log_prob"], rtol=1e-12)
+    acg = gs.ACG(z["mvn_C"])
+    assert np.allclose(acg.log_prob(z["mvn_Y"]), z["acg_log_prob"], rtol=1e-12)
+    assert np.allclose(acg.log_prob(z["mvn_Y"][0]), z["acg_log_prob"][0], rtol=1e-12)
+    with pytest.raises(TypeError):
+        acg._pack()
+    u = gs.Uniform()
+    assert u.log_prob(z["mvn_Y"]) == 0.0 and not np.any(u.gradient(z["mvn_Y"][0]))
+    with pytest.raises(TypeError):
+        u._pack()
+    assert gs.Uniform(5).d == 5 and gs.Uniform(5)._pack()[0] == gs._lib.BINGHAM
+
+
+def test_utils_helpers_against_reference_values():
+    from geosss_amd import utils as U
+    import geosss_amd as gs
+    z = golden("helpers_kat.npz")
+    assert np.array_equal(U.exp(z["clip_in"]), z["clip_exp"])
+    assert np.array_equal(U.log(z["clip_log_in"]), z["clip_log"])
+    assert abs(U.relative_entropy(z["kl_p"], z["kl_q"]) - float(z["kl"])) < 1e-12
+    assert [U.format_time(t) for t in z["format_time_in"]] == list(z["format_time"])
+    assert len(gs.colors) == 5 and all(len(c) == 3 for c in gs.colors)
+
+
+@pytest.mark.gpu
+def test_uniform_target_on_the_device():
+    """Uniform(d) runs on the samplers as the zero Bingham target: every proposal of the shrinkage sampler is accepted at
+    the first try, and the draws are uniform on the sphere (mean ~ 0, second moment ~ I / d)."""
+    import geosss_amd as gs
+    d, n = 6, 4096
+    x0 = gs.sample_sphere(d - 1, n, seed=3)
+    s = gs.ShrinkageSphericalSliceSampler(gs.Uniform(d), x0, seed=5)
+    last = s.sample(40, as_tensor=True)[:, -1, :].cpu()
+    assert s.n_reject == 0
+    assert float(last.mean(0).abs().max()) < 5.0 / np.sqrt(n)
+    assert float((last.T @ last / n - torch.eye(d, dtype=torch.float64) / d).abs().max()) < 5.0 / np.sqrt(n)
+
+
+def test_curve_helpers_against_reference_values():
+    """spherical_curve.py's host helpers: constrained_brownian_curve (same seed -> the reference's knots), SlerpCurve's
+    arc-length tables and evaluation, distance_slerp and find_nearest (the geometry KAT's clipped-end and on-arc cases)."""
+    from geosss_amd.spherical_curve import SlerpCurve, constrained_brownian_curve, distance_slerp
+    z = golden("helpers_kat.npz")
+    for d in (3, 7):
+        knots = constrained_brownian_curve(n_points=12, dimension=d, step_size=0.3, seed=77 + d)
+        assert np.allclose(knots, z[f"cbc_d{d}_knots"], rtol=0, atol=1e-13)
+        curve = SlerpCurve(z[f"cbc_d{d}_knots"])
+        for name in ("theta", "bins", "widths"):
+            assert np.allclose(getattr(curve, name), z[f"cbc_d{d}_{name}"], rtol=0, atol=1e-13)
+        assert np.allclose(curve(z[f"cbc_d{d}_t"]), z[f"cbc_d{d}_points"], rtol=0, atol=1e-12)
+    g = golden("geometry_kat.npz")
+    for d in (3, 10, 50):
+        for q, a, b, dist, near in zip(g[f"d{d}_slerp_q"], g[f"d{d}_slerp_a"], g[f"d{d}_slerp_b"], g[f"d{d}_slerp_dist"],
+                                       g[f"d{d}_slerp_near"]):
+            got_d, got_y = distance_slerp(q, a, b)
+            assert np.allclose(got_y, near, rtol=0, atol=1e-13) and abs(got_d - dist) < 1e-7
+        curve = SlerpCurve(g[f"d{d}_knots"])
+        for q, want in zip(g[f"d{d}_slerp_q"], g[f"d{d}_nearest"]):
+            assert np.allclose(curve.find_nearest(q), want, rtol=0, atol=1e-13)
+
+
+def test_result_files_round_trip_with_the_reference(tmp_path):
+    """geosss_amd.io reads the pickles the reference's scripts write (tests/golden/ref_dump.pkl[.gz], written by
+    geosss.io.dump) and writes the same format; tensors are stored as numpy arrays; the lock directory behaves as the
+    reference's."""
+    import os
+    import pickle
+    from conftest import GOLDEN as GOLDEN_DIR
+    from geosss_amd import io
+    z = golden("helpers_kat.npz")
+    runs = io.load(os.path.join(GOLDEN_DIR, "ref_dump.pkl"))
+    assert sorted(runs) == ["hmc", "rwmh", "sss-reject", "sss-shrink"]
+    for m, v in runs.items():
+        assert np.array_equal(v, z["dump_" + m])
+    table = io.load(os.path.join(GOLDEN_DIR, "ref_dump.pkl.gz"), gzip=True)
+    assert table["n"] == 7 and table["ess"][1:] == [3.5, "text"] and np.array_equal(table["ess"][0], z["dump_rwmh"][0])
+    # what we write: byte-for-byte the reference's plain file for the same object, and readable compressed
+    out = str(tmp_path / "runs.pkl")
+    io.dump(runs, out)
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN_DIR, "ref_dump.pkl"), "rb").read()
+    io.dump({"x": torch.as_tensor(z["dump_hmc"]), "nested": [torch.ones(2), (torch.zeros(1), 4)]}, out + ".gz", gzip=True,
+            lock=True)
+    back = io.load(out + ".gz", gzip=True, lock=True, timeout=1.0)
+    assert isinstance(back["x"], np.ndarray) and np.array_equal(back["x"], z["dump_hmc"])
+    assert isinstance(back["nested"][0], np.ndarray) and isinstance(back["nested"][1][0], np.ndarray)
+    assert not os.path.exists(out + ".gz.lock")
+    with open(out + ".gz", "rb") as f:                         # plain pickle of numpy objects: no torch needed to read it
+        assert b"torch" not in __import__("gzip").decompress(f.read())
+    # a held lock: the second access times out with IOError; a truncated file is an IOError too
+    os.mkdir(out + ".lock")
+    with pytest.raises(IOError):
+        io.load(out, lock=True, timeout=0.05)
+    os.rmdir(out + ".lock")
+    with open(out, "rb") as f:
+        head = f.read(40)
+    with open(out, "wb") as f:
+        f.write(head)
+    with pytest.raises(IOError):
+        io.load(out)
+    assert pickle.HIGHEST_PROTOCOL >= 2
