@@ -192,3 +192,25 @@ def test_result_files_round_trip_with_the_reference(tmp_path):
     with pytest.raises(IOError):
         io.load(out)
     assert pickle.HIGHEST_PROTOCOL >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", ["shrink", "reject"])
+def test_bingham_with_zeroed_matrix_is_uniform(cls):
+    """The reference's tests/test_bingham.py:66-79 (`pdf = gs.random_bingham(d); pdf.A *= 0.0`, then both slice samplers):
+    the edited target is re-uploaded, and every coordinate follows the marginal (1 - t^2)^((d-3)/2) of the uniform
+    distribution -- held here through its second and fourth moments, 1/d and 3/(d (d + 2))."""
+    import geosss_amd as gs
+    d, n = 10, 20000
+    pdf = gs.random_bingham(d)
+    x0 = gs.sample_sphere(d - 1, n, seed=1)
+    warm = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=2)
+    warm.sample(2)                                            # the device copy of the non-zero matrix exists now
+    pdf.A *= 0.0
+    Sampler = gs.ShrinkageSphericalSliceSampler if cls == "shrink" else gs.RejectionSphericalSliceSampler
+    s = Sampler(pdf, x0, seed=3)
+    x = s.sample(30, as_tensor=True)[:, -1, :].cpu().numpy()
+    assert s.n_reject == 0
+    m2, m4 = (x ** 2).mean(0), (x ** 4).mean(0)
+    assert np.max(np.abs(m2 - 1 / d)) < 5 * np.sqrt(2 / (d * d * (d + 2)) / n) + 1e-3
+    assert np.max(np.abs(m4 - 3 / (d * (d + 2)))) < 2e-3
