@@ -9,8 +9,8 @@ namespace gsss {
 int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, bool lane, hipStream_t st)
 {
     // L lanes per chain, Q component quads per lane (d <= 4 Q L), kernels built for 10 and for 17 knots.  Measured at 10^5
-    // chains (tools/bench_curve_sweep.py, 10^9 chain-steps/s): d = 17 .. 32 <4,2> 2.5 against <16,1> 1.7; d = 33 .. 48 <4,3>
-    // 2.2 / 1.6; d = 49 .. 64 <4,4> 2.0 / 1.6 -- the per-step serial work is repeated in 4 instead of 16 lanes, and sixteen
+    // chains (tools/bench_curve_sweep.py, 10^9 chain-steps/s): d = 17 .. 32 <4,2> 2.6 against <16,1> 1.8; d = 33 .. 48 <4,3>
+    // 2.2 / 1.8; d = 49 .. 64 <4,4> 2.1 / 1.8 -- the per-step serial work is repeated in 4 instead of 16 lanes, and sixteen
     // groups share a wavefront.  (<4,4> with 17 knots spills registers: those shapes stay with <16,1>.)
 #define GSSS_SPEC(LL, QQ)                                                                                   \
     do {                                                                                                    \
@@ -25,7 +25,7 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
         return do_curvespec<4, 4, 10>(tb, rb, replay, st);
     }
     if (tb.d <= 64) GSSS_SPEC(16, 1);
-    // d = 65 .. 128, <= 10 knots: eight-lane groups (1.5 / 1.3 against 1.0 for <16,2>)
+    // d = 65 .. 128, <= 10 knots: eight-lane groups (1.6 / 1.4 against 1.2 for <16,2>)
     if (tb.d <= 96 && tb.k <= 10) {
         if (probe) GSSS_PROBE(lane, "curvespec_kernel<8, 3, 10>");
         return do_curvespec<8, 3, 10>(tb, rb, replay, st);
