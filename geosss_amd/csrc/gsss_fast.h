@@ -1022,7 +1022,7 @@ struct CoopBingham {
 };
 
 template <class V, class TP, bool REPLAY>
-__global__ void __launch_bounds__(kBlock, 4) coopfast_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(TargetBlock tb, RunBlock a)
 {
     using Coef = typename TP::Scalar::Coef;
     constexpr int NV = TP::kVectors;

@@ -21,9 +21,17 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
 #undef GSSS_CASE
     // larger d: lanes cooperate on one chain (A must fit the LDS: d <= 128)
     if (tb.d > 10 && tb.d <= 128) {
-        if (probe)
-            GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopBingham>", tb.d <= 16 ? 4 : 16, tb.d <= 64 ? 4 : 8);
+        // Lanes per chain x slots per lane, measured at 10^5 chains (10^9 chain-steps/s, eigenbasis / dense A): d <= 32 four
+        // lanes with eight slots 5.3 / 3.5 against 2.4 / 1.8 for sixteen lanes with four (the per-step serial work -- Philox
+        // and Box-Muller rounds, reductions, the try loop -- is repeated in every lane of a group, and sixteen groups share a
+        // wavefront); d <= 64 eight lanes with eight slots for a diagonal A (3.0 against 2.6), sixteen with four for a dense
+        // one (its d x d products want the lanes: 1.36 against 1.26).
+        const bool diag = tb.k == 1;
+        const int ll = tb.d <= 32 ? 4 : (tb.d <= 64 && diag ? 8 : 16), ss = tb.d <= 16 ? 4 : (tb.d <= 32 || tb.d > 64 || diag ? 8 : 4);
+        if (probe) GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopBingham>", ll, ss);
         if (tb.d <= 16) return do_coopfast<CoopVec<4, 4>, CoopBingham<CoopVec<4, 4>>>(tb, rb, replay, st);
+        if (tb.d <= 32) return do_coopfast<CoopVec<4, 8>, CoopBingham<CoopVec<4, 8>>>(tb, rb, replay, st);
+        if (tb.d <= 64 && diag) return do_coopfast<CoopVec<8, 8>, CoopBingham<CoopVec<8, 8>>>(tb, rb, replay, st);
         if (tb.d <= 64) return do_coopfast<CoopVec<16, 4>, CoopBingham<CoopVec<16, 4>>>(tb, rb, replay, st);
         return do_coopfast<CoopVec<16, 8>, CoopBingham<CoopVec<16, 8>>>(tb, rb, replay, st);
     }

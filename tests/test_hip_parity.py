@@ -296,7 +296,9 @@ SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16
          # d = 64 | 65, 128 | 129, 192 | 193, 256; knot builds 10 | 17; every lane holding normals: d = 13 .. 16, 61 .. 64)
          ("curve", 9, 2), ("curve", 13, 10), ("curve", 16, 10), ("curve", 17, 3), ("curve", 12, 16), ("curve", 61, 10),
          ("curve", 64, 11), ("curve", 65, 10), ("curve", 128, 5), ("curve", 129, 10), ("curve", 192, 17), ("curve", 193, 10),
-         ("curve", 256, 10)]
+         ("curve", 256, 10),
+         # cooperative mixture kernels: slots per lane 4 | 8 | 16 at d = 64 | 65, 128 | 129; up to 256
+         ("vmf", 64, 3), ("vmf", 65, 5), ("vmf", 128, 3), ("vmf", 129, 2), ("vmf", 256, 16)]
 
 
 @pytest.mark.parametrize("kind,d,k", SYNTH)

@@ -22,20 +22,22 @@ def run(label, pdf, d, steps, **kw):
     x0 = gs.sample_sphere_device(d - 1, n, seed=1).T
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0, 3521, **kw)
     s.advance(max(steps // 5, 10))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s.advance(steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = float("inf")
+    for _ in range(3):                                   # best of three: short launches, the clocks settle during the first
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.advance(steps)
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     screen = kw.get("screen", True)
     name = s._lib.gsss_kernel_name(s._target_dev.handle, 1 if s.mode == "fast" else 0, 0 if screen else 100, 1).decode()
     print(f"{label:32s} {n * steps / dt:.3e} chain-steps/s  ({s.mode}: {name})", flush=True)
 
 
-for d in (32, 50, 100):
+for d in (20, 32, 50, 100):
     run(f"bingham eigenbasis d={d}", gs.random_bingham(d, vmax=30.0, vmin=0.0, eigensystem=True, seed=6982), d, 500, mode="fast")
     run(f"bingham dense d={d}", gs.random_bingham(d, vmax=30.0, vmin=0.0, seed=6982), d, 200, mode="fast")
-for d, K in ((32, 5), (100, 5), (200, 3)):
+for d, K in ((20, 5), (32, 5), (50, 5), (64, 3), (100, 5), (128, 10), (200, 3)):
     mus = 100.0 * gs.sample_sphere(d - 1, K, seed=1234)
     run(f"vmf mixture d={d} K={K}", gs.MixtureModel([gs.VonMisesFisher(m) for m in mus]), d, 500, mode="fast")
 for d in (50, 200):
