@@ -44,6 +44,7 @@ for d in (50, 200):
     pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(gs.brownian_curve(10, d, 0.5, seed=4562)), 800.0)
     run(f"curve all-double d={d}", pdf, d, 500, mode="fast", screen=False)
     run(f"curve exact d={d}", pdf, d, 100, mode="exact")
+for d in (50, 100, 200):
+    mus = 100.0 * gs.sample_sphere(d - 1, 5, seed=1234)
+    run(f"vmf mixture exact d={d} K=5", gs.MixtureModel([gs.VonMisesFisher(m) for m in mus]), d, 100, mode="exact")
 run("bingham exact d=50", gs.random_bingham(50, vmax=30.0, vmin=0.0, eigensystem=True, seed=6982), 50, 100, mode="exact")
-mus = 100.0 * gs.sample_sphere(99, 5, seed=1234)
-run("vmf mixture exact d=100 K=5", gs.MixtureModel([gs.VonMisesFisher(m) for m in mus]), 100, 100, mode="exact")
