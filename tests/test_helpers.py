@@ -214,3 +214,21 @@ def test_bingham_with_zeroed_matrix_is_uniform(cls):
     m2, m4 = (x ** 2).mean(0), (x ** 4).mean(0)
     assert np.max(np.abs(m2 - 1 / d)) < 5 * np.sqrt(2 / (d * d * (d + 2)) / n) + 1e-3
     assert np.max(np.abs(m4 - 3 / (d * (d + 2)))) < 2e-3
+
+
+@pytest.mark.gpu
+def test_demo_example_runs():
+    """examples/demo.py -- the reference's demo.ipynb with the import swapped -- runs end to end and reports balanced mode
+    occupancy for the many-chain slice samplers."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "demo.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l for l in r.stdout.splitlines() if "chain-steps/s" in l]
+    assert len(rows) == 2
+    for l in rows:
+        occ = [float(v) for v in re.search(r"mode occupancy \[([^\]]*)\]", l).group(1).split()]
+        assert max(abs(o - 1 / 3) for o in occ) < 0.01
