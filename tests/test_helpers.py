@@ -232,3 +232,48 @@ def test_demo_example_runs():
     for l in rows:
         occ = [float(v) for v in re.search(r"mode occupancy \[([^\]]*)\]", l).group(1).split()]
         assert max(abs(o - 1 / 3) for o in occ) < 0.01
+
+
+def test_sphere_helper_identities():
+    """Size-independent properties of the coordinate maps and great-circle helpers (random inputs, several dimensions)."""
+    from geosss_amd import sphere as S
+    rng = np.random.default_rng(99)
+    X = S.sample_sphere(2, 500, seed=4)
+    phi, theta = S.cartesian2spherical(X)
+    assert np.allclose(S.spherical2cartesian(phi, theta), X, atol=1e-12)            # the maps invert each other on S^2
+    ang = rng.uniform(0, 2 * np.pi, 200)
+    assert np.allclose(S.cartesian2polar(S.polar2cartesian(ang)), ang, atol=1e-12)
+    for d in (3, 7, 40):
+        v = S.sample_sphere(d - 1, seed=d)
+        u = S.sample_subsphere(v, seed=d + 1)
+        x = S.sample_sphere(d - 1, seed=d + 2)
+        assert abs(u @ v) < 1e-14 and abs(np.linalg.norm(u) - 1) < 1e-14             # a unit vector of the great subsphere
+        rot, arc = S.givens(u, v, x), S.slerp(v, x)
+        omega = np.arccos(v @ x)
+        assert np.allclose(rot(0.0), x, atol=1e-15) and np.allclose(rot(2 * np.pi), x, atol=1e-13)
+        assert np.allclose(arc(0.0), v, atol=1e-14) and np.allclose(arc(omega), x, atol=1e-13)
+        for t in rng.uniform(0, 2 * np.pi, 5):
+            y = rot(t)
+            assert abs(np.linalg.norm(y) - 1) < 1e-13                                # rotations keep the sphere
+            assert np.allclose(S.givens(u, v, y)(-t), x, atol=1e-13)                 # and compose
+            z = arc(t * omega / (2 * np.pi))
+            assert abs(np.linalg.norm(z) - 1) < 1e-13
+            assert abs(S.distance(v, z) + S.distance(z, x) - omega) < 1e-7           # on the shortest arc between the two
+        w = S.wrap(rng.standard_normal(d), u, v)
+        assert abs(np.linalg.norm(w) - 1) < 1e-14
+        P = S.orthogonal_projection(rng.standard_normal((20, d)), 3.7 * v)           # the pole need not be a unit vector
+        assert np.max(np.abs(P @ v)) < 1e-13
+    t = S.sample_marginal(10, size=200_000, seed=1)
+    assert abs(np.mean(t)) < 5e-3 and abs(np.mean(t * t) - 0.1) < 2e-3               # a coordinate of the uniform law on S^9
+
+
+@pytest.mark.gpu
+def test_paper_experiments_example_runs():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "paper_experiments.py"), "--chains", "16", "--draws", "400"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("ESS(x_1)") == 16 and "KL on the spiral grid" in r.stdout
