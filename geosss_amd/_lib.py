@@ -12,7 +12,7 @@ MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 VARIANT_FAST_VERIFY = 101
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GsssError(RuntimeError):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "gsss_target_destroy": (C.c_int, [C.c_void_p]),
     "gsss_target_dim": (C.c_int, [C.c_void_p]),
     "gsss_logprob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gsss_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsss_run": (C.c_int, [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]),
     "gsss_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gsss_mode_supported": (C.c_int, [C.c_void_p, C.c_int32]),

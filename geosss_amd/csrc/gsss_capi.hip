@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
 namespace gsss {
 int launch_cpd_run(int variant, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
 int launch_cpd_mh(int variant, int draws, int sampler, const TargetBlock &tb, const RunBlock &rb, const MhBlock &mb, hipStream_t st);
-int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st);
+int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, bool grad, hipStream_t st);
 }  // namespace gsss
 
 static int fast_dispatch(const gsss::TargetBlock &tb, const gsss::RunBlock &rb, bool replay, gsss::FastProbe *probe,
@@ -442,10 +442,10 @@ int gsss_target_destroy(gsss_target *t)
 
 int gsss_target_dim(const gsss_target *t) { return t ? t->tb.d : GSSS_E_INVALID; }
 
-int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *out_dev, void *stream)
+static int logprob_or_gradient(const gsss_target *t, const double *x_dev, int64_t n, double *out_dev, bool grad, void *stream)
 {
     if (!t || n < 0 || (n > 0 && (!x_dev || !out_dev))) {
-        set_error("bad argument to gsss_logprob");
+        set_error(grad ? "bad argument to gsss_gradient" : "bad argument to gsss_logprob");
         return GSSS_E_INVALID;
     }
     if (n == 0) return GSSS_OK;
@@ -455,13 +455,23 @@ int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *o
     if (!guard.ok) return GSSS_E_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (t->tb.kind) {
-    case GSSS_VMF_MIXTURE: return launch_logprob<VmfMixture>(vec, t->tb, x_dev, n, out_dev, st);
-    case GSSS_BINGHAM: return launch_logprob<Bingham>(vec, t->tb, x_dev, n, out_dev, st);
-    case GSSS_CURVE_VMF: return launch_logprob<CurveVmf>(vec, t->tb, x_dev, n, out_dev, st);
-    case GSSS_CPD: return launch_cpd_logprob(t->cpd_variant, t->tb, x_dev, n, out_dev, st);
+    case GSSS_VMF_MIXTURE: return launch_logprob<VmfMixture>(vec, t->tb, x_dev, n, out_dev, grad, st);
+    case GSSS_BINGHAM: return launch_logprob<Bingham>(vec, t->tb, x_dev, n, out_dev, grad, st);
+    case GSSS_CURVE_VMF: return launch_logprob<CurveVmf>(vec, t->tb, x_dev, n, out_dev, grad, st);
+    case GSSS_CPD: return launch_cpd_logprob(t->cpd_variant, t->tb, x_dev, n, out_dev, grad, st);
     }
     set_error("corrupt target");
     return GSSS_E_INVALID;
+}
+
+int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *out_dev, void *stream)
+{
+    return logprob_or_gradient(t, x_dev, n, out_dev, false, stream);
+}
+
+int gsss_gradient(const gsss_target *t, const double *x_dev, int64_t n, double *grad_dev, void *stream)
+{
+    return logprob_or_gradient(t, x_dev, n, grad_dev, true, stream);
 }
 
 int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)

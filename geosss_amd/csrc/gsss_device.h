@@ -1035,8 +1035,8 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
     dr.finish(a, c, active && g == 0);
 }
 
-// Distribution.log_prob for rows of a row-major [n][d] array
-template <class V, template <class> class TT>
+// Distribution.log_prob (GRAD: Distribution.gradient, rows [n][d]) for rows of a row-major [n][d] array
+template <class V, template <class> class TT, bool GRAD>
 __global__ void __launch_bounds__(kBlock) logprob_kernel(TargetBlock tb, const double *__restrict__ xin, int64_t n,
                                                          double *__restrict__ out)
 {
@@ -1057,8 +1057,18 @@ __global__ void __launch_bounds__(kBlock) logprob_kernel(TargetBlock tb, const d
         const int cc = V::comp(g, i);
         x[i] = (cc < d) ? xin[(size_t)c * d + cc] : 0.0;
     }
-    const double p = tgt.logp(x, g, scratch);
-    if (active && g == 0) out[c] = p;
+    if constexpr (GRAD) {
+        double gr[V::N];
+        tgt.grad(x, g, scratch, gr);
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) {
+            const int cc = V::comp(g, i);
+            if (active && cc < d) out[(size_t)c * d + cc] = gr[i];
+        }
+    } else {
+        const double p = tgt.logp(x, g, scratch);
+        if (active && g == 0) out[c] = p;
+    }
 }
 
 }  // namespace gsss

@@ -51,7 +51,7 @@ enum : int { kDrawsPhilox = 0, kDrawsReplay = 1, kDrawsNumpy = 2 };
 template <template <class> class TT>
 int launch_run(int vec_id, int draws, const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
 template <template <class> class TT>
-int launch_logprob(int vec_id, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st);
+int launch_logprob(int vec_id, const TargetBlock &tb, const double *x, int64_t n, double *out, bool grad, hipStream_t st);
 
 void set_error(const char *fmt, ...);
 
@@ -88,7 +88,7 @@ int do_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 }
 
 template <class V, template <class> class TT>
-int do_logprob(const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st)
+int do_logprob(const TargetBlock &tb, const double *x, int64_t n, double *out, bool grad, hipStream_t st)
 {
     using T = TT<V>;
     const size_t lds = (T::lds_doubles(tb.k, tb.d) + scratch_doubles<V, T>()) * sizeof(double);
@@ -96,7 +96,7 @@ int do_logprob(const TargetBlock &tb, const double *x, int64_t n, double *out, h
         set_error("target parameters need %zu B of LDS (> %zu)", lds, kMaxLdsBytes);
         return GSSS_E_UNSUPPORTED;
     }
-    auto kern = logprob_kernel<V, TT>;
+    auto kern = grad ? logprob_kernel<V, TT, true> : logprob_kernel<V, TT, false>;
     if (lds > 48 * 1024)
         GSSS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -120,7 +120,7 @@ int do_logprob(const TargetBlock &tb, const double *x, int64_t n, double *out, h
     }                                                                                                         \
     template <>                                                                                               \
     int launch_logprob<TT>(int vec_id, const TargetBlock &tb, const double *x, int64_t n, double *out,         \
-                           hipStream_t st)                                                                    \
+                           bool grad, hipStream_t st)                                                         \
     {                                                                                                         \
         switch (vec_id) {                                                                                     \
             GSSS_VEC_LIST(GSSS_LOGPROB_CASE_##TT)                                                              \

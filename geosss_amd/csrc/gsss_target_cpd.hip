@@ -252,13 +252,13 @@ int launch_cpd_mh(int variant, int draws, int sampler, const TargetBlock &tb, co
     default: return cpd_rwmh<Cpd24W>(draws, sampler, tb, rb, mb, st);
     }
 }
-int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, hipStream_t st)
+int launch_cpd_logprob(int variant, const TargetBlock &tb, const double *x, int64_t n, double *out, bool grad, hipStream_t st)
 {
     switch (variant) {
-    case 0: return do_logprob<VL4, Cpd8U>(tb, x, n, out, st);
-    case 1: return do_logprob<VL4, Cpd8W>(tb, x, n, out, st);
-    case 2: return do_logprob<VL4, Cpd24U>(tb, x, n, out, st);
-    default: return do_logprob<VL4, Cpd24W>(tb, x, n, out, st);
+    case 0: return do_logprob<VL4, Cpd8U>(tb, x, n, out, grad, st);
+    case 1: return do_logprob<VL4, Cpd8W>(tb, x, n, out, grad, st);
+    case 2: return do_logprob<VL4, Cpd24U>(tb, x, n, out, grad, st);
+    default: return do_logprob<VL4, Cpd24W>(tb, x, n, out, grad, st);
     }
 }
 

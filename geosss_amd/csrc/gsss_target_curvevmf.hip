@@ -9,6 +9,6 @@ namespace gsss {
                                       : do_run<V, CurveVmf, PhiloxDraws>(tb, rb, st);
 #define GSSS_LOGPROB_CASE_CurveVmf(ID, V, NAME) \
     case ID:                             \
-        return do_logprob<V, CurveVmf>(tb, x, n, out, st);
+        return do_logprob<V, CurveVmf>(tb, x, n, out, grad, st);
 GSSS_DEFINE_TARGET_LAUNCHERS(CurveVmf)
 }  // namespace gsss

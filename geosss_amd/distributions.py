@@ -140,11 +140,36 @@ class Distribution:
         out = self._log_prob_device(xt).cpu().numpy()
         return float(out[0]) if x.ndim == 1 else out
 
+    def _gradient_device(self, x):
+        """Distribution.gradient through gsss_gradient (the functions the spherical HMC kernel evaluates): numpy (d,) or (n, d),
+        or a CUDA float64 tensor (n, d) -> the same kind of container."""
+        if isinstance(x, torch.Tensor):
+            if not x.is_cuda:
+                raise ValueError("torch input to gradient must live on the GPU")
+            tgt = self._device_target(x.device)
+            xt = x.to(torch.float64).contiguous()
+            single = xt.ndim == 1
+            xt2 = xt[None] if single else xt
+            if xt2.ndim != 2 or xt2.shape[1] != self.d:
+                raise ValueError(f"expected (..., {self.d}) input")
+            out = torch.empty_like(xt2)
+            dev = _device_index(xt.device)
+            _lib.check(tgt.lib.gsss_gradient(tgt.handle, xt2.data_ptr(), xt2.shape[0], out.data_ptr(), current_stream_ptr(dev)))
+            return out[0] if single else out
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim not in (1, 2) or x.shape[-1] != self.d:
+            raise ValueError(f"expected (d,) or (n, d) input with d={self.d}")
+        _lib.require_device()
+        dev = _device_index(None)
+        out = self._gradient_device(torch.from_numpy(np.ascontiguousarray(np.atleast_2d(x))).to(f"cuda:{dev}")).cpu().numpy()
+        return out[0] if x.ndim == 1 else out
+
     def log_prob(self, x):
         raise NotImplementedError
 
     def gradient(self, x):
-        raise NotImplementedError("gradients are not on the slice sampler's path")
+        """The gradient of log_prob in the ambient space, as the reference's classes define it; evaluated on the device."""
+        return self._gradient_device(x)
 
 
 class VonMisesFisher(Distribution):
@@ -182,8 +207,9 @@ class VonMisesFisher(Distribution):
     def log_prob(self, x):
         return self._log_prob_device(x)
 
+    @counted
     def gradient(self, x):
-        return self.mu
+        return self.mu                                  # distributions.py:159-160 (whatever the shape of x)
 
 
 class _HostDensity(Distribution):
@@ -289,6 +315,13 @@ class MixtureModel(Distribution):
                 return logsumexp(np.stack([p.log_prob(x) for p in self.pdfs], axis=-1) + np.log(self.weights), axis=-1)
         return self._log_prob_device(x)
 
+    @counted
+    def gradient(self, x):
+        """The softmax-weighted mean of the components' gradients (distributions.py:223-227), on the device."""
+        if self._marginal:
+            return _HostDensity._pack(self)
+        return self._gradient_device(x)
+
 
 class Bingham(Distribution):
     """p(x) ~ exp(x^T A x) with symmetric A;  log_prob = sum((x @ A) * x)  (distributions.py:67-86)."""
@@ -320,8 +353,12 @@ class Bingham(Distribution):
     def log_prob(self, x):
         return self._log_prob_device(x)
 
+    @counted
     def gradient(self, x):
-        return 2 * self.A @ x
+        """2 A x (distributions.py:88-89); rows of points and device tensors go through the kernel's own evaluation."""
+        if isinstance(x, torch.Tensor) or np.ndim(x) == 2:
+            return self._gradient_device(x)
+        return 2 * self.A @ np.asarray(x, dtype=np.float64)
 
 
 class BinghamFisher(Bingham):
@@ -341,8 +378,8 @@ class BinghamFisher(Bingham):
     def log_prob(self, x):
         return self._log_prob_device(x)
 
-    def gradient(self, x):
-        return 2 * self.A @ x + self.b
+    # gradient: inherited from Bingham, 2 A x WITHOUT the linear term -- the reference's class does not override it
+    # (distributions.py:106-114), and its spherical HMC therefore runs with that gradient; so does the kernel here.
 
 
 class Uniform(Bingham):
@@ -491,3 +528,8 @@ class CurvedVonMisesFisher(Distribution):
     @counted
     def log_prob(self, x):
         return self._log_prob_device(x)
+
+    @counted
+    def gradient(self, x):
+        """kappa * the nearest point of the curve (distributions.py:277-278), on the device."""
+        return self._gradient_device(x)

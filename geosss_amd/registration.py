@@ -10,16 +10,62 @@ geosss/pointcloud.py they need:
 `log_prob(rotation)` takes a unit quaternion (x, y, z, w) -- the state of the samplers, S^3 -- or rows of them, or a 3x3
 rotation matrix as the reference does, and is evaluated on the GPU (one lane per quaternion; a brute-force scan of the
 source cloud with a register-resident list of the k nearest replaces the reference's per-evaluation KD tree).  The slice
-samplers, MetropolisHastings and SphericalHMC run on these targets (exact mode; `Registration.gradient` is evaluated
-inside the HMC kernel -- there is no host-callable gradient).
-Translations are not part of the sampled state (the reference's samplers never pass one either).
+samplers, MetropolisHastings and SphericalHMC run on these targets (exact mode); `gradient(rotation)` is the function the
+HMC kernel evaluates, callable for rows of quaternions (gsss_gradient).
+Translations are not part of the sampled state (the reference's samplers never pass one either); `log_prob(rotation,
+translation)` and `gradient(rotation, translation)` take one as the reference's do (tests/test_cpd.py there) and evaluate
+on a target moved the other way.
+    RotationMatrix(degree=False).create / rotation2d / rotation3d       pointcloud.py:9-98
 """
+import contextlib
+
 import numpy as np
 
 from . import _lib
 from .distributions import Distribution, _as_f64, counted
 
-__all__ = ["PointCloud", "RotationProjection", "GaussianMixtureModel", "CoherentPointDrift", "quat2matrix", "matrix2quat"]
+__all__ = ["PointCloud", "RotationProjection", "RotationMatrix", "GaussianMixtureModel", "CoherentPointDrift", "quat2matrix",
+           "matrix2quat"]
+
+
+class RotationMatrix:
+    """2 x 2 rotation by an angle, or the intrinsic z-y-z rotation R_z(alpha) R_y(beta) R_z(gamma) of three Euler angles
+    (pointcloud.py:9-98); `degree=True`: `create` takes degrees.  The last matrix made is kept in `.rot_mat`."""
+
+    def __init__(self, degree=False):
+        self.degree = degree
+        self.rot_mat = None
+
+    def create(self, angle):
+        angle = np.asarray(angle, dtype=np.float64)
+        if self.degree:
+            angle = np.deg2rad(angle)
+        if angle.size == 1:
+            return self.rotation2d(float(angle.reshape(())))
+        if angle.size == 3:
+            return self.rotation3d(angle)
+        raise ValueError("Angle vector should be of size 1 or 3")
+
+    @staticmethod
+    def _planar(t):
+        return np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+
+    def rotation2d(self, angle):
+        self.rot_mat = self._planar(angle)
+        return self.rot_mat
+
+    def rotation3d(self, euler_angles):
+        alpha, beta, gamma = (float(a) for a in euler_angles)
+
+        def about_z(t):
+            m = np.eye(3)
+            m[:2, :2] = self._planar(t)
+            return m
+
+        about_y = np.eye(3)
+        about_y[np.ix_([0, 2], [0, 2])] = self._planar(beta).T          # (x, z) plane: [[c, s], [-s, c]]
+        self.rot_mat = about_z(alpha) @ about_y @ about_z(gamma)
+        return self.rot_mat
 
 
 def quat2matrix(q):
@@ -103,7 +149,9 @@ class GaussianMixtureModel(Distribution):
         if tgt.dim != want:
             raise ValueError(f"a {type(src).__name__} source needs a {want}-D target")
         log_volume = float(np.sum(np.log(np.ptp(tgt.positions, 0)))) if self._outlier else 0.0   # registration.py:207-213
-        extra = dict(source=_as_f64(src.positions), source_w=_as_f64(src.weights), target=_as_f64(tgt.positions),
+        shift = getattr(self, "_shift", None)
+        positions = tgt.positions if shift is None else tgt.positions - shift
+        extra = dict(source=_as_f64(src.positions), source_w=_as_f64(src.weights), target=_as_f64(positions),
                      target_w=_as_f64(tgt.weights), n_target=tgt.size, target_dim=tgt.dim, k_nn=self.k,
                      outlier=int(self._outlier), sigma=self.sigma, beta=self.beta, omega=self.omega, log_volume=log_volume)
         return _lib.CPD, 4, src.size, 0.0, (None, None, None, None), extra
@@ -115,15 +163,35 @@ class GaussianMixtureModel(Distribution):
             return matrix2quat(r)
         return r
 
+    @contextlib.contextmanager
+    def _shifted(self, translation):
+        """A translation of the transformed source is the opposite translation of the target (the score depends on the
+        differences only, and the outlier box on the target's extent): evaluate on a target moved by -translation.  The
+        sampled state stays the rotation, as in the reference's scripts; a translated model is a second device target."""
+        t = None if translation is None else np.asarray(translation, dtype=np.float64)
+        if t is not None and t.shape != (self.target.dim,):
+            raise ValueError(f"translation must have {self.target.dim} components")
+        if t is None or not np.any(t != 0):
+            yield
+            return
+        self._shift = t
+        try:
+            yield
+        finally:
+            self._shift = None
+
     @counted
     def log_prob(self, rotation, translation=None):
         """beta * score of the pose (registration.py:47-53); `rotation`: quaternion (4,), rows (n, 4) or a 3x3 matrix."""
-        if translation is not None and np.any(np.asarray(translation) != 0):
-            raise NotImplementedError("translations are not part of the sampled state")
-        return self._log_prob_device(self._as_quaternions(rotation))
+        with self._shifted(translation):
+            return self._log_prob_device(self._as_quaternions(rotation))
 
     def gradient(self, rotation, translation=None):
-        raise NotImplementedError("Registration.gradient (registration.py:55-60) is evaluated inside the HMC kernel only")
+        """The gradient of the score with respect to the unit quaternion (registration.py:55-60: posterior weights, the 3 x 3
+        gradient with respect to R, the quaternion Jacobian of pointcloud.py:135-204) -- what the spherical HMC kernel evaluates;
+        `rotation`: quaternion (4,) or rows (n, 4)."""
+        with self._shifted(translation):
+            return self._gradient_device(self._as_quaternions(rotation))
 
 
 class CoherentPointDrift(GaussianMixtureModel):
@@ -138,6 +206,5 @@ class CoherentPointDrift(GaussianMixtureModel):
 
     @counted
     def log_prob(self, rotation, translation=None):
-        if translation is not None and np.any(np.asarray(translation) != 0):
-            raise NotImplementedError("translations are not part of the sampled state")
-        return self._log_prob_device(self._as_quaternions(rotation))
+        with self._shifted(translation):
+            return self._log_prob_device(self._as_quaternions(rotation))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 7
+#define GSSS_ABI_VERSION 8
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -219,6 +219,11 @@ int gsss_target_dim(const gsss_target *t);
 /* Distribution.log_prob for n points (distributions.py:84-86, :156-157, :218-221, :272-275).
  * x_dev is ROW-major [n][d] (numpy's natural layout for pdf.log_prob(samples)). */
 int gsss_logprob(const gsss_target *t, const double *x_dev, int64_t n, double *out_dev, void *stream);
+
+/* Distribution.gradient for n points (distributions.py:88-89 Bingham 2 A x -- also what BinghamFisher inherits --, :159-160
+ * vMF mu, :223-227 mixture, :277-278 curve kappa * nearest; registration.py:55-60 the pose score's gradient with respect to the
+ * quaternion): the functions the spherical HMC kernel evaluates (GSSS_HMC), for rows of x_dev [n][d] -> grad_dev [n][d]. */
+int gsss_gradient(const gsss_target *t, const double *x_dev, int64_t n, double *grad_dev, void *stream);
 
 /* The sampler (see gsss_run_args). */
 int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);

@@ -591,6 +591,30 @@ def make_helpers():
         ts = np.concatenate([[0.0, 1.0], rng.uniform(0, 1, 14), curve.bins[3:5]])
         a[f"cbc_d{d}_t"] = ts
         a[f"cbc_d{d}_points"] = curve(ts)
+    # registration with a translation, after the reference's tests/test_cpd.py: the cube, a z-y-z rotation, noise, outliers
+    from geosss.pointcloud import PointCloud, RotationMatrix, RotationProjection, matrix2quat
+    from geosss.registration import CoherentPointDrift
+    cube = np.array([[x, y, z] for z in (-1, 1) for y in (-1, 1) for x in (-1, 1)], dtype=float)
+    R_true = RotationMatrix().rotation3d(np.array([0.2, 0.3, 0.1]))
+    a["cpdt_R"], a["cpdt_q"] = R_true, matrix2quat(R_true)
+    a["cpdt_euler_deg"] = np.array([10.0, 20.0, 30.0])
+    a["cpdt_R_deg"] = RotationMatrix(degree=True).create(a["cpdt_euler_deg"])
+    a["cpdt_R_2d"] = RotationMatrix().rotation2d(0.7)
+    qs = rsphere.sample_sphere(3, 6, seed=77)
+    a["cpdt_qs"] = qs
+    for tag, src, t_true in (("3d", PointCloud(cube), np.array([0.5, -0.3, 0.2])),
+                             ("2d", RotationProjection(cube), np.array([0.5, -0.3]))):
+        tgt = src.transform_positions(R_true, t_true) + rng.normal(0, 0.05, (8, len(t_true)))
+        tgt = np.vstack([tgt, rng.uniform(-3, 3, (4, len(t_true)))])
+        a[f"cpdt_{tag}_target"], a[f"cpdt_{tag}_t"] = tgt, t_true
+        for w in (0.0, 0.2, 0.4):
+            cpd = CoherentPointDrift(PointCloud(tgt), src, sigma=0.5, k=8, beta=1.0, omega=w)
+            key = f"cpdt_{tag}_w{int(10 * w)}"
+            a[key + "_logp_true"] = np.float64(cpd.log_prob(R_true, t_true))
+            a[key + "_logp_identity"] = np.float64(cpd.log_prob(np.eye(3), np.zeros(len(t_true))))
+            a[key + "_logp_qs"] = np.array([cpd.log_prob(q, t_true) for q in qs])
+            a[key + "_grad_qs"] = np.array([cpd.gradient(q, t_true) for q in qs])
+            a[key + "_grad_qs_not"] = np.array([cpd.gradient(q) for q in qs])
     # result files as the reference's scripts write them (geosss/io.py: pickle protocol 2, plain and gzip)
     from geosss.io import dump
     runs = {m: rng.standard_normal((3, 5, 4)) for m in ("sss-reject", "sss-shrink", "rwmh", "hmc")}

@@ -277,3 +277,62 @@ def test_paper_experiments_example_runs():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("ESS(x_1)") == 16 and "KL on the spiral grid" in r.stdout
+
+
+HMC_FIXTURES = ["mh_hmc_bingham_d10_vmax30", "mh_hmc_bingham_d5_dense", "mh_hmc_binghamfisher_d5", "mh_hmc_cpd_cube_3d2d",
+                "mh_hmc_cpd_protein", "mh_hmc_curve_d10_kappa800", "mh_hmc_curve_d50_kappa800", "mh_hmc_gmm_protein_k10",
+                "mh_hmc_vmfmix_d10_k5_kappa100", "mh_hmc_vmfmix_readme"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", HMC_FIXTURES)
+def test_device_gradient_known_answers(name):
+    """Distribution.gradient on the device (gsss_gradient: the functions the spherical HMC kernel evaluates) against the
+    gradients the reference returned at the same points (`grad_X` -> `grad` of the HMC fixtures): one row, a batch, a device
+    tensor.  BinghamFisher: the reference's class inherits Bingham's 2 A x -- its linear term does not enter."""
+    from helpers import product_target
+    z = golden(name + ".npz")
+    X, want = z["grad_X"], z["grad"]
+    assert len(X) > 0
+    pdf = product_target(z)
+    scale = np.maximum(1.0, np.abs(want))
+    got = pdf.gradient(X)
+    assert got.shape == want.shape and np.max(np.abs(got - want) / scale) < 1e-9
+    assert np.max(np.abs(pdf.gradient(X[0]) - want[0]) / scale[0]) < 1e-9
+    on_dev = pdf.gradient(torch.as_tensor(X).cuda())
+    assert on_dev.is_cuda and np.array_equal(on_dev.cpu().numpy(), got)
+    with pytest.raises(ValueError):
+        pdf.gradient(np.zeros(pdf.d + 1))
+
+
+@pytest.mark.gpu
+def test_registration_with_translation_after_reference_test_cpd():
+    """The reference's tests/test_cpd.py on the device: the cube, a z-y-z rotation, a translation, noise and outliers;
+    log_prob(R, t) and gradient(q, t) equal the reference's values (helpers_kat.npz), the true pose scores above the identity,
+    and the gradient agrees with finite differences of log_prob."""
+    from scipy.optimize import approx_fprime
+    from geosss_amd.pointcloud import PointCloud, RotationMatrix, RotationProjection, matrix2quat
+    from geosss_amd.registration import CoherentPointDrift
+    z = golden("helpers_kat.npz")
+    cube = np.array([[x, y, zz] for zz in (-1, 1) for y in (-1, 1) for x in (-1, 1)], dtype=float)
+    R_true = RotationMatrix().rotation3d(np.array([0.2, 0.3, 0.1]))
+    assert np.allclose(R_true, z["cpdt_R"], atol=1e-15) and np.allclose(matrix2quat(R_true), z["cpdt_q"], atol=1e-15)
+    assert np.allclose(RotationMatrix(degree=True).create(z["cpdt_euler_deg"]), z["cpdt_R_deg"], atol=1e-15)
+    assert np.allclose(RotationMatrix().rotation2d(0.7), z["cpdt_R_2d"], atol=1e-15)
+    qs = z["cpdt_qs"]
+    for tag, src in (("3d", PointCloud(cube)), ("2d", RotationProjection(cube))):
+        t_true = z[f"cpdt_{tag}_t"]
+        for w in (0.0, 0.2, 0.4):
+            key = f"cpdt_{tag}_w{int(10 * w)}"
+            cpd = CoherentPointDrift(PointCloud(z[f"cpdt_{tag}_target"]), src, sigma=0.5, k=8, beta=1.0, omega=w)
+            lp_true, lp_id = cpd.log_prob(R_true, t_true), cpd.log_prob(np.eye(3), np.zeros(len(t_true)))
+            assert abs(lp_true - float(z[key + "_logp_true"])) < 1e-9 and abs(lp_id - float(z[key + "_logp_identity"])) < 1e-9
+            assert lp_true > lp_id
+            assert np.allclose(cpd.log_prob(qs, t_true), z[key + "_logp_qs"], rtol=0, atol=1e-9)
+            assert np.allclose(cpd.gradient(qs, t_true), z[key + "_grad_qs"], rtol=1e-9, atol=1e-9)
+            assert np.allclose(cpd.gradient(qs), z[key + "_grad_qs_not"], rtol=1e-9, atol=1e-9)
+            q_true = matrix2quat(R_true)
+            numeric = approx_fprime(q_true, lambda q: cpd.log_prob(q, t_true), epsilon=1e-6)
+            assert np.max(np.abs(cpd.gradient(q_true, t_true) - numeric)) < 1e-3 * max(1.0, np.max(np.abs(numeric)))
+            with pytest.raises(ValueError):
+                cpd.log_prob(q_true, np.zeros(len(t_true) + 1))
