@@ -94,7 +94,9 @@ class Distribution:
 
     def _pack(self):
         """-> (kind, d, k, kappa, (mu, logc, A, knots))"""
-        raise NotImplementedError
+        raise TypeError(f"{type(self).__name__} has no device parameter block: the samplers run inside HIP kernels and cannot call a "
+                        "Python log_prob; built-in targets are VonMisesFisher, MixtureModel (of vMF components), Bingham, "
+                        "BinghamFisher, CurvedVonMisesFisher, Uniform, CoherentPointDrift and GaussianMixtureModel")
 
     def _device_target(self, device=None):
         dev = _device_index(device)

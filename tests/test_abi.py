@@ -146,3 +146,19 @@ def test_script_conveniences(caplog):
     assert not any("quiet" in r.getMessage() for r in caplog.records)
     d = gs.sphere.distance(np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0]]))
     assert np.allclose(d, [np.pi / 2, 0.0])
+
+
+def test_custom_python_distribution_is_refused_with_a_clear_message():
+    """The reference's samplers take any object with a Python log_prob; the kernels cannot call Python: a subclass without a
+    device parameter block is refused by name, before anything is launched."""
+    import pytest
+    import geosss_amd as gs
+
+    class Mine(gs.Distribution):
+        d = 3
+
+        def log_prob(self, x):
+            return 0.0
+
+    with pytest.raises(TypeError, match="no device parameter block"):
+        Mine()._pack()
