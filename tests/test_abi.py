@@ -162,3 +162,14 @@ def test_custom_python_distribution_is_refused_with_a_clear_message():
 
     with pytest.raises(TypeError, match="no device parameter block"):
         Mine()._pack()
+
+
+def test_graft_entry_build_passes():
+    """`__graft_entry__.build()` -- the driver's "does it build" check -- compiles, loads and checks the ABI it was built with."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=root, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-1500:]
