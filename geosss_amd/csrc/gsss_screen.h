@@ -71,6 +71,8 @@ __device__ __forceinline__ float log2_32(double v)
 //                              them again from x and u when the chain is taken up (same operations, same bits).  Wide
 //                              mixtures: 2 K floats = 40 % of the parked state, one more workgroup per CU without them
 //   kMinWaves                  wavefronts per SIMD the kernel is built for (__launch_bounds__)
+//   kTradeMin                  a lane swaps its stopped chain for its parked one when at least this many lanes of the
+//                              wavefront want to (or none can try): the swap runs for the whole wavefront whoever takes part
 //   decide(x, u, U, c, s)      = level_exact(c, s) > threshold, the all-double decision of an undecided try
 // ------------------------------------------------------------------------------------------
 template <int D, int KC>
@@ -83,6 +85,10 @@ struct ScreenVmf : FastVmf<D, KC> {
     // of three wavefronts per SIMD asked of the compiler: 170 -> 168)
     static constexpr int kParkSkip = KC >= 6 ? 2 * KC : 0;  // (K = 3: 36.5 against 34.8 ms with it -- four workgroups per CU fit anyway)
     static constexpr int kMinWaves = KC >= 6 ? 3 : 1;
+    // K >= 6 forms the 2 K coefficients again at take-up (kParkSkip), which makes a swap as dear as a pair of tries: swapping only
+    // when 24 lanes want to is worth 9 % (K = 10, kappa = 500: 56.6 -> 51.7 ms per 10^9 chain-steps; 12: 52.5, 32: 59.2, 44: 71.7);
+    // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
+    static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
     __device__ __forceinline__ void refill(const double (&x)[D], const double (&u)[D], float (&q)[kCoef32Floats]) const
     {
         constexpr double L = 1.4426950408889634074;
@@ -208,7 +214,7 @@ struct ScreenBingham : FastBingham<D> {
     using Base = FastBingham<D>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 6;
-    static constexpr int kParkSkip = 0, kMinWaves = 1;
+    static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
@@ -380,7 +386,7 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Base = FastCurve<D, NK>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
-    static constexpr int kParkSkip = 0, kMinWaves = 1;
+    static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     Curve32<NK> c32;
     __host__ __device__ static size_t lds_doubles() { return Base::lds_doubles() + 2 * (size_t)(NK - 1); }
@@ -799,7 +805,12 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
     bool stuck = false;
     for (;;) {
         // a lane whose current chain cannot try (stopped, waiting or finished) takes its other chain when that one can
-        if (kPark && cur.status != kReady && parked_status == kReady) trade();
+        if (TP::kTradeMin > 1) {
+            const bool want = kPark && cur.status != kReady && parked_status == kReady;
+            const unsigned long long wants = __ballot(want), can = __ballot(cur.status == kReady);
+            if (want && (__popcll(wants) >= TP::kTradeMin || can == 0ull)) trade();
+        } else if (kPark && cur.status != kReady && parked_status == kReady)
+            trade();
         const unsigned long long trying = __ballot(cur.status == kReady);
         if (cur.status == kReady) attempt();
         const unsigned long long live = __ballot(cur.status != kDone || parked_status != kDone);

@@ -16,13 +16,21 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def newest(pattern):
+    """gpurun merges a call's files into gpurun_out/ beside those of earlier calls: of several runs of one pass, the last"""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = {}
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
     wl = os.path.basename(d)[len(f"prof_{tag}_"):]
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for sub in ("fetch", "write"):
-        for f in glob.glob(f"{d}/{sub}/**/*_counter_collection.csv", recursive=True):
+        for f in newest(f"{d}/{sub}/**/*_counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if not vals:
@@ -42,7 +50,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
                           "mode": cfg.get("mode")},
                "source": f"profiles/{tag}_{wl}_summary.md (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes)"}
     shutil.copy(os.path.join(d, "summary.md"), os.path.join(ROOT, "profiles", f"{tag}_{wl}_summary.md"))
-    for f in glob.glob(f"{d}/trace/**/*_kernel_stats.csv", recursive=True):
+    for f in newest(f"{d}/trace/**/*_kernel_stats.csv"):
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
