@@ -12,7 +12,8 @@ MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 VARIANT_FAST_VERIFY = 101
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
-ABI_VERSION = 8
+ABI_VERSION = 9
+STATS_NO_SECOND_MOMENT = 1
 
 
 class GsssError(RuntimeError):
@@ -38,7 +39,9 @@ class RunArgs(C.Structure):
                 ("stats_lags", C.c_int32), ("stats_dev", C.c_void_p), ("stats_dirs_dev", C.c_void_p),
                 ("stats_modes", C.c_int32), ("n_leapfrog", C.c_int32), ("stepsize_dev", C.c_void_p),
                 ("n_accept_dev", C.c_void_p), ("momenta_dev", C.c_void_p), ("adapt_steps", C.c_int64),
-                ("mixing_probability", C.c_double), ("adapt_left_dev", C.c_void_p), ("n_rwmh_dev", C.c_void_p)]
+                ("mixing_probability", C.c_double), ("adapt_left_dev", C.c_void_p), ("n_rwmh_dev", C.c_void_p),
+                ("momenta_samples_dev", C.c_void_p), ("stepsize_trace_dev", C.c_void_p), ("stats_flags", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 # symbol -> (restype, argtypes); must list every function include/gsss.h declares
@@ -52,7 +55,7 @@ SIGNATURES = {
     "gsss_logprob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsss_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsss_run": (C.c_int, [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]),
-    "gsss_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gsss_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gsss_mode_supported": (C.c_int, [C.c_void_p, C.c_int32]),
     "gsss_variant_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "gsss_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

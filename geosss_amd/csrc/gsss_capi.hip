@@ -526,7 +526,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     }
     const int vec = a->mode == GSSS_MODE_FAST ? 0 : select_vec(t->tb.d, a->variant);
     if (vec < 0) return vec;
-    RunBlock rb;
+    RunBlock rb{};
     rb.state = a->state_dev;
     rb.samples = a->samples_dev;
     rb.n_reject = a->n_reject_dev;
@@ -554,26 +554,16 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     rb.stats_dirs = a->stats_dirs_dev;
     rb.stats_lags = a->stats_lags;
     rb.stats_modes = a->stats_modes;
+    rb.stats_flags = a->stats_flags;
     if (a->stats_dev != nullptr) {
-        if (!a->stats_dirs_dev || a->stats_lags < 0 || a->stats_modes < 0 || a->stats_lags > 4096 || a->stats_modes > 4096) {
-            set_error("stats_dev needs stats_dirs_dev, 0 <= stats_lags <= 4096 and 0 <= stats_modes <= 4096");
+        if (!a->stats_dirs_dev || a->stats_lags < 0 || a->stats_modes < 0 || a->stats_lags > 4096 || a->stats_modes > 4096 ||
+            (a->stats_flags & ~GSSS_STATS_NO_SECOND_MOMENT)) {
+            set_error("stats_dev needs stats_dirs_dev, 0 <= stats_lags <= 4096, 0 <= stats_modes <= 4096 and known stats_flags");
             return GSSS_E_INVALID;
         }
-        bool lane;
-        if (a->mode == GSSS_MODE_FAST) {
-            FastProbe pr;
-            RunBlock rbp{};
-            if (fast_dispatch(t->tb, rbp, false, &pr, nullptr) != GSSS_OK) return GSSS_E_UNSUPPORTED;
-            lane = pr.lane;
-        } else {
-            int nv;
-            const VecInfo *v = vec_table(&nv);
-            lane = false;
-            for (int i = 0; i < nv; ++i)
-                if (v[i].id == vec) lane = v[i].L == 1;
-        }
-        if (!lane) {
-            set_error("running statistics are accumulated by the lane-per-chain kernels only (this shape runs a cooperative one)");
+        // the lane-group layouts form the d (d + 1) / 2 second-moment sums through cross-lane reads: small d only
+        if (!(a->stats_flags & GSSS_STATS_NO_SECOND_MOMENT) && t->tb.d > 64) {
+            set_error("second moments are accumulated for d <= 64 (d (d + 1) / 2 rows per chain): set GSSS_STATS_NO_SECOND_MOMENT");
             return GSSS_E_UNSUPPORTED;
         }
     }
@@ -615,6 +605,8 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         mb.mix_alpha = a->mixing_probability;
         mb.adapt_left = a->adapt_left_dev;
         mb.n_rwmh = a->n_rwmh_dev;
+        mb.momenta_samples = a->sampler == GSSS_HMC ? a->momenta_samples_dev : nullptr;
+        mb.stepsize_trace = a->sampler == GSSS_HMC ? nullptr : a->stepsize_trace_dev;
         if (t->tb.kind == GSSS_CPD) return launch_cpd_mh(t->cpd_variant, draws, a->sampler, t->tb, rb, mb, st);
         switch (t->tb.kind) {
         case GSSS_VMF_MIXTURE: return launch_mh<VmfMixture>(vec, draws, a->sampler, t->tb, rb, mb, st);
@@ -640,10 +632,11 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     return GSSS_E_INVALID;
 }
 
-int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags)
+int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags, int32_t flags)
 {
-    if (d < 2 || n_modes < 0 || n_lags < 0) return GSSS_E_INVALID;
-    return 1 + 2 * (int64_t)d + (int64_t)d * (d + 1) / 2 + 2 + n_modes + 2 + 3 * (int64_t)n_lags;
+    if (d < 2 || n_modes < 0 || n_lags < 0 || (flags & ~GSSS_STATS_NO_SECOND_MOMENT)) return GSSS_E_INVALID;
+    const int64_t second = (flags & GSSS_STATS_NO_SECOND_MOMENT) ? 0 : (int64_t)d * (d + 1) / 2;
+    return 1 + 2 * (int64_t)d + second + 2 + n_modes + 2 + 3 * (int64_t)n_lags;
 }
 
 int gsss_mode_supported(const gsss_target *t, int32_t mode)

@@ -81,7 +81,7 @@ __device__ __forceinline__ bool curvespec_decide(const FastCurve<1, NK> &scl, co
     return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
 }
 
-template <int L, int Q, int NK, bool REPLAY>
+template <int L, int Q, int NK, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
     using V = CoopVec<L, 4 * Q>;
@@ -142,13 +142,23 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
     const int g = lane % L;              // lane of the group
     const int base = lane - g;           // first lane of the group in the wavefront
     const int64_t n = a.n_chains;
-    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / L) + threadIdx.x / L;
-    const bool active = c_raw < n;
-    const int64_t c = active ? c_raw : n - 1;
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int nq = (d + 3) >> 2;         // Philox blocks of the normals
     const uint32_t try_base = 1u + (uint32_t)nq;
     const int max_tries = a.max_tries;
+
+    // This workgroup's work: the whole launch of the chunk of kBlock / L chains it was launched for -- or, sliced (a.sched,
+    // SliceSched in gsss_device.h), the (chunk, step slice) of the ticket it draws.
+    __shared__ uint32_t sched_word[4];
+    const bool sliced = a.sched != nullptr;
+    uint32_t chunk = blockIdx.x;
+    int32_t s_begin = 0, len = (int32_t)a.n_steps;  // (fast mode: < 2^31 steps per launch)
+    bool timed_out = false;
+    if (sliced && !SliceSched::take(a, kBlock / L, sched_word, chunk, s_begin, len, timed_out)) return;  // (one ticket per workgroup: never)
+    const uint64_t step0 = a.step_offset + (uint64_t)s_begin;  // global id of the item's first step
+    const int64_t c_raw = (int64_t)chunk * (kBlock / L) + threadIdx.x / L;
+    const bool active = c_raw < n;
+    const int64_t c = active ? c_raw : n - 1;
 
     double x[N];
 #pragma unroll
@@ -165,8 +175,16 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
     // (kRecur: a_i . x is carried from step to step in the group's LDS words coef[0 .. NK), advanced by lane 0)
     float lvl_c = 0.0f, e_c = 0.0f;  // single-precision level of the accepted point and its error bound, carried to the next step
     int64_t n_try = 0;
-    int32_t steps_done = 0, until_keep = (int32_t)a.thin, row_out = 0;
-    bool alive = active && a.n_steps > 0;
+    // (a chain that is alive has made every step so far: retained rows follow from the slice's first step)
+    int32_t steps_done = 0, until_keep = (int32_t)a.thin - s_begin % (int32_t)a.thin, row_out = s_begin / (int32_t)a.thin;
+    bool alive = active && len > 0;
+    if (sliced) {
+        if (SliceSched::dead(a, kBlock / L)[c] != 0) alive = false;  // stopped with an error flag in an earlier slice of this launch
+        if (timed_out && alive) {              // cannot happen (SliceSched::take); never compute from a state that is not there
+            err |= GSSS_CHAIN_MAX_TRIES | GSSS_CHAIN_COUNTER_SATURATED;
+            alive = false;
+        }
+    }
 
     auto wave_sync = [&]() {  // LDS words written by some lanes of the wavefront, read by others
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -186,7 +204,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
         }
     };
 
-    for (int64_t s = 0; s < a.n_steps; ++s) {
+    for (int32_t s = 0; s < len; ++s) {
         if (!__any(alive)) break;
         // The target's constants never change, so the compiler would hoist their LDS loads out of this loop and keep them
         // in registers for the whole launch: the base is made opaque once per step.
@@ -223,7 +241,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
             u_thr = take();
             u_th0 = shrink ? take() : 0.0;
         } else {
-            dr.begin_step(a.step_offset + (uint64_t)s);
+            dr.begin_step(step0 + (uint64_t)s);
 #pragma unroll
             for (int iq = 0; iq < Q; ++iq) {
                 const int quad = g + L * iq;
@@ -263,17 +281,13 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
         // ---------------- a_r . u = (a_r . w) / |w|, a_r . x; single-precision pack; the doubles parked for decide()
-        const bool refresh = !kRecur || s == 0 || ((a.step_offset + (uint64_t)s) % kCoefRefresh) == 0;
+        const bool refresh = !kRecur || s == 0 || ((step0 + (uint64_t)s) % kCoefRefresh) == 0;
         float q[Curve32<NK>::kFloats];
         {
             double pw = 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
             const double rnw = inv_norm(group_sum<L>(pw));
-            constexpr int kParked = (NK + L - 1) / L;
-            double park_u[kParked], park_x[kParked];
-#pragma unroll
-            for (int j = 0; j < kParked; ++j) park_u[j] = park_x[j] = 0.0;
 #pragma unroll
             for (int r = 0; r < NK; ++r) {
                 const double *row = knots + (size_t)r * DPAD;
@@ -288,20 +302,13 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
                 const double axr = refresh ? group_sum<L>(px) : coef[r];
                 q[r] = (float)axr;
                 q[NK + r] = (float)au;
-                if (g == r % L) {  // lane r mod L parks knot r's pair for decide() and the recurrence (a select here, one store below)
-                    park_u[r / L] = au;
-                    park_x[r / L] = axr;
-                }
+                // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
+                // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
+                // the pair to one owner lane (round 2: 40 of the step's vector instructions)
+                coef[NK + r] = au;
+                if (refresh) coef[r] = axr;
                 // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
                 if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < kParked; ++j) {
-                const int r = g + L * j;
-                if (r < NK) {
-                    coef[NK + r] = park_u[j];
-                    if (refresh) coef[r] = park_x[j];
-                }
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -442,13 +449,16 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
                 for (int r = 0; r < NK; ++r) coef[r] = fma(cs, coef[r], sn * coef[NK + r]);  // a . x' = c a.x + s a.u
             }
             ++steps_done;
-            if (a.samples != nullptr && --until_keep == 0) {
+            if ((a.samples != nullptr || STATS) && --until_keep == 0) {
                 until_keep = (int32_t)a.thin;
+                if (a.samples != nullptr) {
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const int cc = V::comp(g, i);
-                    if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
+                    for (int i = 0; i < N; ++i) {
+                        const int cc = V::comp(g, i);
+                        if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
+                    }
                 }
+                if constexpr (STATS) stats_update_group<V>(a, c, g, d, x);  // (`alive` is the same in every lane of a group)
                 ++row_out;
             }
         }
@@ -465,8 +475,10 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
             if (a.n_reject) a.n_reject[c] += n_try - steps_done;
             if (a.n_tries) a.n_tries[c] += n_try;
             if (a.err && err) a.err[c] |= err;
+            if (a.sched != nullptr && err) SliceSched::dead(a, kBlock / L)[c] = 1;  // (every error flag of this kernel stops the chain)
         }
     }
+    if (a.sched != nullptr) SliceSched::publish(a, sched_word);
 }
 
 template <int L, int Q, int NK>
@@ -482,6 +494,13 @@ int do_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStre
     }
     const size_t lds = curvespec_lds_doubles<L, Q, NK>() * sizeof(double);
     auto kern = replay ? curvespec_kernel<L, Q, NK, true> : curvespec_kernel<L, Q, NK, false>;
+    if (rb.stats != nullptr) {  // running statistics: a build of its own (the plain kernel carries none of it)
+        if (replay) {
+            set_error("running statistics are not accumulated from a replayed stream by the group kernels");
+            return GSSS_E_UNSUPPORTED;
+        }
+        kern = curvespec_kernel<L, Q, NK, false, true>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -491,9 +510,15 @@ int do_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStre
         }
     }
     const int64_t per_block = kBlock / L;
-    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
+    // more chunks than the chip holds at once: a grid of the resident workgroups takes (chunk, step slice) tickets (SliceSched)
+    const SlicePlan plan = plan_slices(kern, lds, rb, n_chunks, !replay, st);
+    RunBlock rbl = rb;
+    rbl.sched = plan.ws;
+    rbl.slice_steps = plan.slice_steps;
+    hipLaunchKernelGGL(kern, dim3((unsigned)plan.grid), dim3(kBlock), lds, st, tb, rbl);
     hipError_t e = hipGetLastError();
+    if (plan.ws) (void)hipFreeAsync(plan.ws, st);
     if (e != hipSuccess) {
         set_error("curvespec kernel launch failed: %s", hipGetErrorString(e));
         return GSSS_E_HIP;

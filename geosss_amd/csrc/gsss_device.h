@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gsss.h"
 #include "gsss_math.h"
@@ -49,7 +50,142 @@ struct RunBlock {
     double *stats;             // NULL or [gsss_stats_rows][n_chains] running statistics of the retained series
     const double *stats_dirs;  // [2 + stats_modes][d]: projection w, hop direction h, mode directions
     int32_t stats_lags, stats_modes;
+    int32_t stats_flags;       // GSSS_STATS_* (row layout of `stats`)
+    // Slice scheduling (kernels that support it; NULL: one workgroup per chunk of chains runs the whole launch).  A launch whose
+    // chunks do not fit the chip at once runs its last, partial round of workgroups on a nearly empty chip; sliced, the grid has
+    // one workgroup per (chunk, step slice), every workgroup draws its item from a ticket counter, slice-major, and a chunk's
+    // state travels from slice to slice through HBM (SliceSched below): the dispatcher refills a slot whenever a slice ends, and
+    // the chip drains for one slice, not for a whole chunk.  Zeroed workspace: [0] ticket | [2 ..) progress[n_chunks] | dead[n_chains].
+    uint32_t *sched;
+    int32_t slice_steps;       // steps per slice; boundaries sit at multiples of it in GLOBAL step ids
 };
+
+// ------------------------------------------------------------------------------------------
+// Slice scheduler.  The workgroup that draws ticket t works on (slice t / n_chunks, chunk t % n_chunks); slice k of a chunk
+// starts when slice k - 1 has been published.  Tickets, not blockIdx: the predecessor's ticket was drawn earlier, so its
+// workgroup is resident or done whatever order the dispatcher starts workgroups in, and it waits for nothing drawn later -- the
+// wait always ends.  In slice-major order the predecessor was drawn n_chunks tickets earlier, so with n_chunks > resident
+// workgroups the wait is over before it begins; it is still a real acquire: the chunk's state, counters and statistics rows were
+// written by another CU (MI355X_MICROARCH.md, inter-workgroup visibility: plain stores -> every wave's s_waitcnt vmcnt(0) ->
+// barrier -> lane 0: agent release, s_waitcnt, relaxed flag store; consumer: relaxed poll -> agent acquire -> s_waitcnt vmcnt(0)
+// -> barrier -> plain loads).  Slice boundaries are multiples of slice_steps in global step ids (the first slice of a launch
+// runs up to the next one), a multiple of kCoefRefresh, so a kernel that refreshes carried quantities at those steps computes
+// the same bits sliced or not.  A wait that does not end (cannot happen) gives up after ~3 s and flags the chains.
+// ------------------------------------------------------------------------------------------
+struct SliceSched {
+    // (no state of its own: everything follows from the launch arguments, so that nothing of it stays in registers while a
+    // slice runs -- the kernels that use it have no scalar register to spare)
+    __device__ static __forceinline__ uint32_t chunks(const RunBlock &a, int per_block) { return (uint32_t)((a.n_chains + per_block - 1) / per_block); }
+    __device__ static __forceinline__ uint32_t *progress(const RunBlock &a) { return a.sched + 2; }
+    __device__ static __forceinline__ int32_t *dead(const RunBlock &a, int per_block)
+    {
+        return reinterpret_cast<int32_t *>(a.sched + 2 + chunks(a, per_block));
+    }
+    // workgroup-uniform; false: no such item.  `word`: three LDS words of the workgroup (the ticket; chunk and slice rest there
+    // until publish()).  s_begin, len: the slice's steps within the launch; timed_out: the predecessor never arrived.
+    __device__ static __forceinline__ bool take(const RunBlock &a, int per_block, uint32_t *word, uint32_t &chunk, int32_t &s_begin,
+                                                int32_t &len, bool &timed_out)
+    {
+        if (threadIdx.x == 0) *word = __hip_atomic_fetch_add(a.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)*word);
+        const uint32_t n_chunks = chunks(a, per_block);
+        const int32_t ss = a.slice_steps, n_steps = (int32_t)a.n_steps;
+        const int32_t first_len = ss - (int32_t)(a.step_offset % (uint64_t)ss);
+        const int32_t rest = n_steps - first_len;
+        const uint32_t n_items = n_chunks * (uint32_t)(1 + (rest > 0 ? (rest + ss - 1) / ss : 0));
+        if (t >= n_items) return false;
+        const uint32_t slice = t / n_chunks;
+        chunk = t - slice * n_chunks;
+        if (threadIdx.x == 0) {
+            word[1] = chunk;
+            word[2] = slice;
+        }
+        s_begin = slice == 0 ? 0 : first_len + (int32_t)(slice - 1) * ss;
+        int32_t s_end = first_len + (int32_t)slice * ss;
+        s_end = s_end < n_steps ? s_end : n_steps;
+        len = s_end - s_begin;
+        timed_out = false;
+        if (slice > 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t spins = 0, ok = 1;
+                while (__hip_atomic_load(progress(a) + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < slice) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > (1u << 22)) {
+                        ok = 0;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                *word = ok;
+            }
+            __syncthreads();
+            timed_out = __builtin_amdgcn_readfirstlane((int)*word) == 0;
+        }
+        return true;
+    }
+    // after the chunk's stores: make them visible, then publish the slice
+    __device__ static __forceinline__ void publish(const RunBlock &a, const uint32_t *word)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(progress(a) + word[1], word[2] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+constexpr size_t slice_sched_bytes(int64_t n_chunks, int64_t n_chains) { return 4 * (size_t)(2 + n_chunks + n_chains); }
+
+// Host side: should this launch be sliced, and on how many workgroups?  Sliced when the chunks do not fit the chip at once (a
+// last, partial round would otherwise run on a nearly empty chip: measured 15 % of the curve kernels' time at 10^5 chains) and
+// there are at least two slices.  The workspace is allocated, zeroed and freed in stream order; a failed allocation falls back
+// to one workgroup per chunk.  GSSS_SLICE_STEPS: steps per slice (a multiple of 64; 0 turns slicing off).
+struct SlicePlan {
+    uint32_t *ws = nullptr;
+    int64_t grid = 0;
+    int32_t slice_steps = 0;
+};
+template <class Kern>
+inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, int64_t n_chunks, bool allowed, hipStream_t st)
+{
+    SlicePlan p;
+    p.grid = n_chunks;
+    if (!allowed) return p;
+    const char *env = getenv("GSSS_SLICE_STEPS");  // (read per launch: tests switch it)
+    const int env_val = env ? atoi(env) : 128;  // (measured at 10^5 chains x 1000 steps, d = 10 / 50 / 200: 64 -> 24.1 / 40.0 / 107.3 ms, 128 -> 23.8 / 39.7 / 106.1)
+    const int env_steps = env_val > 0 ? ((env_val + 63) / 64) * 64 : 0;
+    if (env_steps <= 0 || rb.n_steps < 2 * (int64_t)env_steps) return p;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
+        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        return p;
+    }
+    const int64_t resident = (int64_t)per_cu * cus;
+    const int64_t n_slices = 2 + rb.n_steps / env_steps;
+    if (n_chunks <= resident || n_chunks * n_slices >= 0x7FFFFFFFll || rb.n_chains >= 0x7FFFFFFFll) return p;
+    const size_t bytes = slice_sched_bytes(n_chunks, rb.n_chains);
+    void *ws = nullptr;
+    if (hipMallocAsync(&ws, bytes, st) != hipSuccess || ws == nullptr) {
+        (void)hipGetLastError();
+        return p;
+    }
+    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFreeAsync(ws, st);
+        return p;
+    }
+    const int64_t first_len = env_steps - (int64_t)(rb.step_offset % (uint64_t)env_steps), rest = rb.n_steps - first_len;
+    p.ws = static_cast<uint32_t *>(ws);
+    p.grid = n_chunks * (1 + (rest > 0 ? (rest + env_steps - 1) / env_steps : 0));  // = SliceSched::take's n_items
+    p.slice_steps = env_steps;
+    return p;
+}
 
 // address of component j of retained row `row` of chain c
 __device__ __forceinline__ size_t sample_index(const RunBlock &a, int64_t row, int j, int d, int64_t c)
@@ -75,7 +211,8 @@ __device__ __forceinline__ void stats_update(const RunBlock &a, int64_t c, const
     const size_t n = (size_t)a.n_chains;
     double *s = a.stats + c;
     const int K = a.stats_modes, L = a.stats_lags;
-    constexpr int T = D * (D + 1) / 2;
+    const bool second = !(a.stats_flags & GSSS_STATS_NO_SECOND_MOMENT);
+    const int T = second ? D * (D + 1) / 2 : 0;
     const int r_prev = 1, r_sum = 1 + D, r_xx = 1 + 2 * D, r_dist = r_xx + T, r_hop = r_dist + 1, r_mode = r_hop + 1;
     const int r_p = r_mode + K, r_lag = r_p + 2, r_ring = r_lag + L, r_head = r_ring + L;
     const double *w = a.stats_dirs, *h = a.stats_dirs + D, *modes = a.stats_dirs + 2 * D;
@@ -103,8 +240,10 @@ __device__ __forceinline__ void stats_update(const RunBlock &a, int64_t c, const
     for (int i = 0; i < D; ++i) {
         s[(size_t)(r_prev + i) * n] = x[i];
         s[(size_t)(r_sum + i) * n] += x[i];
+        if (second) {
 #pragma unroll
-        for (int j = i; j < D; ++j) s[(size_t)(r_xx + t++) * n] += x[i] * x[j];
+            for (int j = i; j < D; ++j) s[(size_t)(r_xx + t++) * n] += x[i] * x[j];
+        }
     }
     if (K > 0) {
         int best = 0;
@@ -301,6 +440,103 @@ __device__ __forceinline__ double vdot(const double (&a)[V::N], const double (&b
 #pragma unroll
     for (int i = 0; i < V::N; ++i) s = fma(a[i], b[i], s);
     return V::reduce(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Running statistics for the lane-GROUP layouts (CoopVec: L lanes hold the components of one chain): the same rows and
+// definitions as stats_update above.  Every lane of the group calls it with its own slots; the dots are group sums, lane 0
+// of the group keeps the scalar rows, every lane the rows of its own components.  The second moments need every pair of
+// components: the other lanes' slots are fetched lane by lane (ds_bpermute) -- a statistics build only, and only while
+// GSSS_STATS_NO_SECOND_MOMENT is off (d (d + 1) / 2 rows: the host side leaves them out beyond d = 16).
+// ------------------------------------------------------------------------------------------
+template <class V>
+__device__ __forceinline__ void stats_update_group(const RunBlock &a, int64_t c, int g, int d, const double (&x)[V::N])
+{
+    constexpr int N = V::N, LG = V::L;
+    const size_t n = (size_t)a.n_chains;
+    double *s = a.stats + c;
+    const int K = a.stats_modes, L = a.stats_lags;
+    const bool second = !(a.stats_flags & GSSS_STATS_NO_SECOND_MOMENT);
+    const int T = second ? d * (d + 1) / 2 : 0;
+    const int r_prev = 1, r_sum = 1 + d, r_xx = 1 + 2 * d, r_dist = r_xx + T, r_hop = r_dist + 1, r_mode = r_hop + 1;
+    const int r_p = r_mode + K, r_lag = r_p + 2, r_ring = r_lag + L, r_head = r_ring + L;
+    const double *w = a.stats_dirs, *h = a.stats_dirs + d, *modes = a.stats_dirs + 2 * d;
+    const int64_t cnt = (int64_t)s[0];
+    double p = 0.0, xh = 0.0, dot = 0.0, ph = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int cc = V::comp(g, i);
+        if (cc < d) {
+            p = fma(x[i], w[cc], p);
+            xh = fma(x[i], h[cc], xh);
+            if (cnt > 0) {
+                const double pj = s[(size_t)(r_prev + cc) * n];
+                dot = fma(pj, x[i], dot);
+                ph = fma(pj, h[cc], ph);
+            }
+        }
+    }
+    p = V::reduce(p);
+    xh = V::reduce(xh);
+    dot = V::reduce(dot);
+    ph = V::reduce(ph);
+    if (cnt > 0 && g == 0) {
+        s[(size_t)r_dist * n] += acos(fmin(fmax(dot, -1.0), 1.0));
+        const int sa = (xh > 0.0) - (xh < 0.0), sb = (ph > 0.0) - (ph < 0.0);  // np.sign
+        if (sa != sb) s[(size_t)r_hop * n] += 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int cc = V::comp(g, i);
+        if (cc < d) {
+            s[(size_t)(r_prev + cc) * n] = x[i];
+            s[(size_t)(r_sum + cc) * n] += x[i];
+        }
+    }
+    if (second) {  // pair (ci <= cj) lives in row r_xx + ci d - ci (ci - 1) / 2 + (cj - ci)
+        const int base = (int)(threadIdx.x % 64) - g;
+        for (int jl = 0; jl < LG; ++jl) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double xj = __shfl(x[j], base + jl);
+                const int cj = V::comp(jl, j);
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const int ci = V::comp(g, i);
+                    if (cj < d && ci <= cj) s[(size_t)(r_xx + ci * d - ci * (ci - 1) / 2 + (cj - ci)) * n] += x[i] * xj;
+                }
+            }
+        }
+    }
+    if (K > 0) {
+        int best = 0;
+        double bv = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int cc = V::comp(g, i);
+                if (cc < d) v = fma(x[i], modes[(size_t)k * d + cc], v);
+            }
+            v = V::reduce(v);
+            if (v > bv) {  // first maximum, like np.argmax
+                bv = v;
+                best = k;
+            }
+        }
+        if (g == 0) s[(size_t)(r_mode + best) * n] += 1.0;
+    }
+    if (g == 0) {
+        s[(size_t)r_p * n] += p;
+        s[(size_t)(r_p + 1) * n] += p * p;
+        if (L > 0) {
+            const int64_t lmax = cnt < L ? cnt : L;
+            for (int64_t l = 1; l <= lmax; ++l) s[(size_t)(r_lag + l - 1) * n] += p * s[(size_t)(r_ring + (cnt - l) % L) * n];
+            s[(size_t)(r_ring + cnt % L) * n] = p;
+            if (cnt < L) s[(size_t)(r_head + cnt) * n] = p;
+        }
+        s[0] = (double)(cnt + 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1012,8 +1248,13 @@ __global__ void __launch_bounds__(kBlock) run_kernel(TargetBlock tb, RunBlock a)
                     if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
                 }
             }
-            if constexpr (STATS && V::L == 1) {  // (cooperative layouts: refused by gsss_run)
-                if (active && !step_err) stats_update<V::N>(a, c, x);
+            if constexpr (STATS) {
+                if (active && !step_err) {  // (group layouts: `active` and `step_err` are the same in every lane of a group)
+                    if constexpr (V::L == 1)
+                        stats_update<V::N>(a, c, x);
+                    else
+                        stats_update_group<V>(a, c, g, d, x);
+                }
             }
             ++row;
         }

@@ -1021,7 +1021,7 @@ struct CoopBingham {
     __device__ __forceinline__ double level0(typename Scalar::Coef &cf, double, bool) const { return cf.qxx + cf.bx; }
 };
 
-template <class V, class TP, bool REPLAY>
+template <class V, class TP, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(TargetBlock tb, RunBlock a)
 {
     using Coef = typename TP::Scalar::Coef;
@@ -1195,14 +1195,17 @@ __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(Ta
                 for (int r = 0; r < NV; ++r) cf.ax[r] = fma(cs, cf.ax[r], sn * cf.au[r]);
             }
             ++steps_done;
-            if (a.samples != nullptr && --until_keep == 0) {
+            if ((a.samples != nullptr || STATS) && --until_keep == 0) {
                 until_keep = a.thin;
-                if (active) {
+                if (active && a.samples != nullptr) {
 #pragma unroll
                     for (int i = 0; i < V::N; ++i) {
                         const int cc = V::comp(g, i);
                         if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
                     }
+                }
+                if constexpr (STATS) {
+                    if (active) stats_update_group<V>(a, c, g, d, x);  // (`active` is the same in every lane of a group)
                 }
                 ++row;
             }
@@ -1237,6 +1240,13 @@ int do_coopfast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStrea
         return GSSS_E_UNSUPPORTED;
     }
     auto kern = replay ? coopfast_kernel<V, TP, true> : coopfast_kernel<V, TP, false>;
+    if (rb.stats != nullptr) {  // running statistics: a build of its own (the plain kernel carries none of it)
+        if (replay) {
+            set_error("running statistics are not accumulated from a replayed stream by the cooperative kernels");
+            return GSSS_E_UNSUPPORTED;
+        }
+        kern = coopfast_kernel<V, TP, false, true>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -11,7 +11,7 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, Fa
 {
     // (knot counts: what the all-double / one-wavefront kernels below cover too, so that a shape is either served in every
     // placement and variant or in none)
-    const bool spec = rb.screen && !rb.spread && rb.rng_state == nullptr && rb.stats == nullptr && tb.k >= 2 &&
+    const bool spec = rb.screen && !rb.spread && rb.rng_state == nullptr && tb.k >= 2 &&
                       tb.k <= (tb.d > 64 ? 17 : 16) && tb.d >= 9 && tb.d <= 256;
     // lane-per-chain kernels: the listed dimensions, any curve of 2 .. 10 knots (built for 10; FastCurve pads)
 #define GSSS_CASE(D)                                                \

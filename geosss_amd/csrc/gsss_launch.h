@@ -74,9 +74,7 @@ int do_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
         return GSSS_E_UNSUPPORTED;
     }
     auto kern = run_kernel<V, TT, DR, false>;
-    if constexpr (V::L == 1) {  // running statistics: a second build of the lane kernels, so that the plain ones carry none of it
-        if (rb.stats != nullptr) kern = run_kernel<V, TT, DR, true>;
-    }
+    if (rb.stats != nullptr) kern = run_kernel<V, TT, DR, true>;  // running statistics: a second build, so that the plain kernels carry none of it
     if (lds > 48 * 1024)
         GSSS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

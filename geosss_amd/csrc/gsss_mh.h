@@ -21,6 +21,8 @@ struct MhBlock {
     double mix_alpha;     // GSSS_MIX: probability of the RWMH proposal
     int64_t *adapt_left;  // GSSS_MIX: [n_chains] in/out, RWMH proposals that still adapt the stepsize
     int64_t *n_rwmh;      // GSSS_MIX: [n_chains] or NULL, ADDED to
+    double *momenta_samples;  // HMC: NULL or the momenta of the retained rows, laid out like RunBlock::samples (mcmc.py:321-332)
+    double *stepsize_trace;   // RWMH kernels: NULL or [n_steps][n_chains], the stepsize after every RWMH proposal, NaN otherwise (mcmc.py:228)
 };
 
 template <class V, template <class> class TT, template <class> class DR, int SAMPLER>
@@ -140,13 +142,18 @@ __global__ void __launch_bounds__(kBlock) mh_kernel(TargetBlock tb, RunBlock a, 
         } else if (s < m.adapt_steps) {
             eps *= accepted ? 1.02 : 0.98;                        // mcmc.py:113-115
         }
+        if (SAMPLER == GSSS_RWMH && m.stepsize_trace != nullptr && active && g == 0)
+            m.stepsize_trace[(size_t)s * n + c] = use_rwmh ? eps : __builtin_nan("");  // mcmc.py:228 (after the adaptation)
         if (a.samples != nullptr && --until_keep == 0) {
             until_keep = a.thin;
             if (active) {
 #pragma unroll
                 for (int i = 0; i < V::N; ++i) {
                     const int cc = V::comp(g, i);
-                    if (cc < d) a.samples[sample_index(a, row, cc, d, c)] = x[i];
+                    if (cc < d) {
+                        a.samples[sample_index(a, row, cc, d, c)] = x[i];
+                        if (SAMPLER == GSSS_HMC && m.momenta_samples) m.momenta_samples[sample_index(a, row, cc, d, c)] = v[i];
+                    }
                 }
             }
             ++row;

@@ -277,7 +277,18 @@ struct Curve32 {
     int nseg;
     double kappa;
     static constexpr int kFloats = 2 * NK + 2;
-    // max over the segments of the clipped y . nearest, single precision
+    // max over the segments of the clipped y . nearest, single precision.
+    // Per segment (a, b) the reference takes t* = atan2(B, A), clips it to [0, theta_g] and evaluates y . p(t) there
+    // (spherical_curve.py:10-32): a.y f for t* <= 0, b.y f for t* >= theta_g, |P y| / (sin theta_g + 1e-10) in between, with
+    // f = sin / (sin + 1e-10).  Round 3: the MAXIMUM over the segments needs less than that per segment.  Every knot that
+    // starts a segment counts as it is: the segment it starts gives at least a.y f in each of its three branches (interior:
+    // the amplitude of y . p(t); t* > theta_g: b.y > a.y), so max_g >= a_i.y f for every i < nseg -- and a knot is the b of
+    // the segment before it, so the "b" branch of every segment but the last adds nothing new.  What is left per segment: the
+    // interior value where 0 < t* < theta_g (B > 0 and A >= cos theta_g |(A, B)|), and for the LAST segment its b end where
+    // the reference's rule picks it.  Same value as the reference's maximum up to f (1e-10 / sin theta_g relative: in the
+    // margin, eval_error); continuous across the branch boundaries (t* = 0: |P y| / sin = a.y; t* = theta_g: = b.y), so the
+    // Lipschitz bound of the margin holds whichever branch the single-precision evaluation takes.  16 instead of 34 vector
+    // instructions a segment (no three-way select, v_sqrt instead of v_rsq and two products).
     __device__ __forceinline__ float best32(const float (&q)[kFloats], float c, float s) const
     {
         float best = -INFINITY;
@@ -289,24 +300,21 @@ struct Curve32 {
             const float ct = sg.x, st = sg.y, rden = sg.z;
             const float A = ay * st;
             const float B = fmaf(-ay, ct, by);
-            const float h2 = fmaf(A, A, B * B);
-            // (straight-line: all three candidates are formed and selected -- left to short-circuit operators and nested
-            // conditionals the compiler builds three levels of exec-mask branches per segment)
-            const float rs = __builtin_amdgcn_rsqf(h2);
-            const float rh = h2 > 0.0f ? rs : 0.0f;
-            const bool at_a = (B < 0.0f) | ((B == 0.0f) & (A >= 0.0f));
-            const bool at_b = A * rh < ct;
-            const float n_a = st * ay, n_b = st * by, n_i = h2 * rh;
-            float num = at_b ? n_b : n_i;
-            num = at_a ? n_a : num;
-            const float xc = fminf(fmaxf(num * rden, -1.0f), 1.0f);
-            best = fmaxf(best, g < nseg ? xc : -INFINITY);
+            const float h = __builtin_amdgcn_sqrtf(fmaf(A, A, B * B));
+            const bool before_b = A >= ct * h;                   // t* <= theta_g
+            const bool inside = (B > 0.0f) & before_b;
+            float v = inside ? h * rden : ay;
+            if (g == nseg - 1) {                                 // (uniform) the last segment: b where the reference clips to it
+                const bool at_a = (B < 0.0f) | ((B == 0.0f) & (A >= 0.0f));
+                v = fmaxf(v, (!before_b & !at_a) ? by : -INFINITY);
+            }
+            best = fmaxf(best, g < nseg ? v : -INFINITY);
             ay = by;
             // two segments at a time (they pair up in v_pk_* instructions); all NK - 1 side by side cost 8 more registers
             // where the callers have none to spare (measured, d = 10 / 50: 30.8 / 64.2 -> 29.8 / 60.9 ms)
             if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        return best;
+        return fminf(best, 1.0f);  // (the reference clips every y . nearest to [-1, 1]; the maximum of unit vectors' dots is >= -1)
     }
     // error bound of one best32 evaluation with the coefficients q[0 .. 2 NK)
     __device__ __forceinline__ float eval_error(const float (&q)[kFloats]) const
@@ -315,7 +323,7 @@ struct Curve32 {
 #pragma unroll
         for (int i = 0; i < NK; ++i) b = fmaxf(b, fabsf(q[i]) + fabsf(q[NK + i]));
         const float delta = b * (kSinCosErr32 + 3.0f * kUnit32);                // error of a.y
-        return (3.0f * delta + 40.0f * kUnit32) * inv_sin_min * 1.05f;          // see finish32
+        return (3.0f * delta + 40.0f * kUnit32 + 2.0e-10f) * inv_sin_min * 1.05f;  // see finish32; 2e-10: the factor f of best32
     }
     // finish32 with the single-precision level of x supplied by the caller (lvl0: within e_lvl0 of the double-precision
     // level of x over kappa -- e.g. the value best32 gave for the accepted try of the previous step) and log U taken in
@@ -344,7 +352,7 @@ struct Curve32 {
         // error of a.y: (|a.x| + |a.u|) (eps + 2^-24) + the fma roundings
         const float delta = b * (kSinCosErr32 + 3.0f * kUnit32);
         // one evaluation: 3 delta Lipschitz + ~16 roundings of values <= 2, all over sin(theta_g); v_rsq_f32 relative 2^-22
-        const float e_eval = (3.0f * delta + 40.0f * kUnit32) * inv_sin_min * 1.05f;
+        const float e_eval = (3.0f * delta + 40.0f * kUnit32 + 2.0e-10f) * inv_sin_min * 1.05f;
         // thr / kappa = level32(x) / kappa + log(U) / kappa: the level of x is evaluated by the same routine at theta = 0
         const float lvl0 = best32(q, 1.0f, 0.0f);
         const double tau = (double)lvl0 + fm::log_fast(u_thr) / kappa;

@@ -76,7 +76,7 @@ constexpr int kSpecRows = 4;        // tries evaluated per iteration
 constexpr int kSpecPrefetched = 16; // try uniforms drawn with the normals
 
 // NV = number of values of the big reduction (>= k + 1, multiple of 4); k <= NV - 1 knots
-template <int NV, bool REPLAY>
+template <int NV, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBlock a)
 {
     using V = CoopVec<64, 4>;
@@ -391,13 +391,16 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
         ax0 = fma(acs, ax0, asn * au0);                                  // a . x' = c a.x + s a.u
         ax1 = fma(acs, ax1, asn * au1);
         ++steps_done;
-        if (a.samples != nullptr && --until_keep == 0) {
+        if ((a.samples != nullptr || STATS) && --until_keep == 0) {
             until_keep = a.thin;
+            if (a.samples != nullptr) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cc = 4 * lane + i;
-                if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
+                for (int i = 0; i < 4; ++i) {
+                    const int cc = 4 * lane + i;
+                    if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
+                }
             }
+            if constexpr (STATS) stats_update_group<V>(a, c, lane, d, x);
             ++row_out;
         }
     }
@@ -424,6 +427,13 @@ int do_curve64(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream
     const size_t lds = ((size_t)tb.k * 256 + 4 * (size_t)(tb.k - 1) + (size_t)(kSpecPrefetched + 4 + NV) * (kBlock / 64) + kTabLds) *
                        sizeof(double);
     auto kern = replay ? curve64_kernel<NV, true> : curve64_kernel<NV, false>;
+    if (rb.stats != nullptr) {  // running statistics: a build of its own
+        if (replay) {
+            set_error("running statistics are not accumulated from a replayed stream by the one-wavefront curve kernel");
+            return GSSS_E_UNSUPPORTED;
+        }
+        kern = curve64_kernel<NV, false, true>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -138,6 +138,14 @@ def grid_kl(pdf, samples, n_saff=1500, eps=1e-12):
     return _back(kl[0] if single else kl, samples)
 
 
+def pair_sum_went_negative(ac):
+    """Whether the pair-sum rule of utils.py:119-131 found its stopping point inside the given lags (per series)."""
+    ac = _t(ac)
+    m = ac.shape[-1]
+    tail = ac[..., 2:-1] if m % 2 != 0 else ac[..., 2:]
+    return (tail.reshape(*tail.shape[:-1], -1, 2).sum(-1) < 0).any(-1)
+
+
 def iat_from_acf(ac):
     """The IAT heuristic of utils.py:119-131 applied to a given autocorrelation (lags 0 .. m-1 along the last
     axis): adjacent-pair sums from lag 2, truncated at the first negative pair."""
@@ -154,15 +162,18 @@ def iat_from_acf(ac):
     return 1.0 + torch.clamp(2.0 * (ac * keep).sum(-1), min=0.0)
 
 
-def from_running(acc, d, n_modes, n_lags):
+def from_running(acc, d, n_modes, n_lags, second_moment=True):
     """Diagnostics from the running statistics the sampler kernels accumulate (include/gsss.h: gsss_run_args.stats_dev;
     rows x chains).  Per chain, with the reference's definitions on the retained series:
-        n, mean (d), second_moment (d, d), geodesic_step (sphere.distance of consecutive draws, mean),
+        n, mean (d), second_moment (d, d; absent when the rows were left out: GSSS_STATS_NO_SECOND_MOMENT),
+        geodesic_step (sphere.distance of consecutive draws, mean),
         hopping_frequency (scripts/bingham.py:23-25), mode_occupancy (K; scripts/vMF_diagnostics.py:335-342),
         acf (lags 0 .. L of the projection, the direct estimator utils.acf, utils.py:96-110 -- identical to
-        diagnostics.acf(series, n_max=L+1)), iat / n_eff (pair-sum heuristic of utils.py:119-134 on that acf)."""
+        diagnostics.acf(series, n_max=L+1)), iat / n_eff (pair-sum heuristic of utils.py:119-134 on that acf),
+        iat_truncated (True where no adjacent pair of the L lags went negative: the sum stopped at the window's end and
+        the IAT is a LOWER bound -- raise `lags` or thin more)."""
     acc = _t(acc).to(torch.float64)
-    T = d * (d + 1) // 2
+    T = d * (d + 1) // 2 if second_moment else 0
     r_sum, r_xx = 1 + d, 1 + 2 * d
     r_dist = r_xx + T
     r_hop, r_mode = r_dist + 1, r_dist + 2
@@ -170,11 +181,12 @@ def from_running(acc, d, n_modes, n_lags):
     r_lag, r_ring, r_head = r_p + 2, r_p + 2 + n_lags, r_p + 2 + 2 * n_lags
     n = acc[0]
     out = {"n": n, "mean": (acc[r_sum:r_sum + d] / n).T}
-    sm = torch.zeros((acc.shape[1], d, d), dtype=torch.float64, device=acc.device)
-    iu = torch.triu_indices(d, d)
-    sm[:, iu[0], iu[1]] = (acc[r_xx:r_xx + T] / n).T
-    sm[:, iu[1], iu[0]] = (acc[r_xx:r_xx + T] / n).T
-    out["second_moment"] = sm
+    if second_moment:
+        sm = torch.zeros((acc.shape[1], d, d), dtype=torch.float64, device=acc.device)
+        iu = torch.triu_indices(d, d)
+        sm[:, iu[0], iu[1]] = (acc[r_xx:r_xx + T] / n).T
+        sm[:, iu[1], iu[0]] = (acc[r_xx:r_xx + T] / n).T
+        out["second_moment"] = sm
     out["geodesic_step"] = acc[r_dist] / (n - 1)
     out["hopping_frequency"] = acc[r_hop] / (n - 1)
     if n_modes:
@@ -198,4 +210,5 @@ def from_running(acc, d, n_modes, n_lags):
         out["acf"] = ac
         out["iat"] = iat_from_acf(ac)
         out["n_eff"] = n / out["iat"]
+        out["iat_truncated"] = ~pair_sum_went_negative(ac)
     return out

@@ -149,14 +149,16 @@ class RejectionSphericalSliceSampler:
         self._stats = None
 
     # ------------------------------------------------------------------ running statistics
-    def enable_stats(self, lags=32, projection=None, hop=None, modes=None):
+    def enable_stats(self, lags=32, projection=None, hop=None, modes=None, second_moment=None):
         """Accumulate running statistics of the retained series inside the sampler kernels (gsss_run_args.stats_dev):
         moments, geodesic step between consecutive draws, hopping frequency across the equator of `hop`, occupancy
         of `modes`, and the lag sums of the projection x . `projection` from which the reference's autocorrelation
         (utils.py:96-110) and its IAT / n_eff heuristic (:119-134) follow -- without storing a single draw.
         Statistics are taken at the cadence of `advance(..., thin=t)` (every t-th state), like diagnostics computed
         from a thinned stored chain.  Defaults: projection = first coordinate; hop = the target's `.mode` if it has
-        one; modes = the component means of a MixtureModel.  Lane-per-chain kernels only (d <= 10 in exact mode)."""
+        one; modes = the component means of a MixtureModel.  second_moment: keep the d (d + 1) / 2 sums of x_i x_j too
+        (default: for d <= 16; they grow as d^2 -- 20 100 rows per chain at d = 200).  Every slice-sampler kernel family
+        accumulates them (lane, lane-group and cooperative layouts)."""
         d = self.d
         w = np.zeros(d) if projection is None else np.asarray(projection, dtype=np.float64)
         if projection is None:
@@ -171,10 +173,12 @@ class RejectionSphericalSliceSampler:
         dirs = np.concatenate([w[None], np.asarray(hop, dtype=np.float64)[None], modes], axis=0)
         if dirs.shape[1] != d:
             raise ValueError("projection / hop / modes must have d components")
-        rows = int(self._lib.gsss_stats_rows(d, len(modes), int(lags)))
+        second_moment = d <= 16 if second_moment is None else bool(second_moment)
+        flags = 0 if second_moment else _lib.STATS_NO_SECOND_MOMENT
+        rows = int(self._lib.gsss_stats_rows(d, len(modes), int(lags), flags))
         if rows < 0:
             raise ValueError("bad statistics shape")
-        self._stats = {"lags": int(lags), "modes": len(modes),
+        self._stats = {"lags": int(lags), "modes": len(modes), "flags": flags,
                        "dirs": torch.from_numpy(np.ascontiguousarray(dirs)).to(self._tdev),
                        "acc": torch.zeros((rows, self.n_chains), dtype=torch.float64, device=self._tdev)}
         return self
@@ -184,7 +188,8 @@ class RejectionSphericalSliceSampler:
         if self._stats is None:
             raise ValueError("call enable_stats() first")
         from . import diagnostics
-        return diagnostics.from_running(self._stats["acc"], self.d, self._stats["modes"], self._stats["lags"])
+        return diagnostics.from_running(self._stats["acc"], self.d, self._stats["modes"], self._stats["lags"],
+                                        second_moment=not (self._stats["flags"] & _lib.STATS_NO_SECOND_MOMENT))
 
     def _numpy_states(self, seed):
         """[n_chains, 4] PCG64 words (state_hi, state_lo, inc_hi, inc_lo), one default_rng per chain:
@@ -362,7 +367,7 @@ class RejectionSphericalSliceSampler:
         if self._stats is not None and stats:
             a.stats_dev = self._stats["acc"].data_ptr()
             a.stats_dirs_dev = self._stats["dirs"].data_ptr()
-            a.stats_lags, a.stats_modes = self._stats["lags"], self._stats["modes"]
+            a.stats_lags, a.stats_modes, a.stats_flags = self._stats["lags"], self._stats["modes"], self._stats["flags"]
         _lib.check(self._lib.gsss_run(self._target_dev.handle, C.byref(a), self._stream()))
         self._step += int(n_steps)
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 8
+#define GSSS_ABI_VERSION 9
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -73,6 +73,9 @@ extern "C" {
 #define GSSS_CHAIN_REPLAY_EXHAUSTED 4 /* replay stream shorter than the draws consumed */
 #define GSSS_CHAIN_COUNTER_SATURATED 8 /* fast mode counts the proposals of ONE launch in 32 bits: more than 2^32-1 of them
                                           in a single gsss_run call leave n_tries/n_reject too small (split the call) */
+
+/* gsss_run_args.stats_flags */
+#define GSSS_STATS_NO_SECOND_MOMENT 1 /* stats_dev has no sum x_i x_j rows (T = 0 below): they grow as d^2 -- 20 100 rows at d = 200 */
 
 typedef struct gsss_target gsss_target; /* opaque; owns a small device parameter block */
 
@@ -163,12 +166,12 @@ typedef struct gsss_run_args {
                                   (64 chains per wavefront: throughput), 2 = spread (one chain per wavefront: chains of a
                                   small ensemble do not wait for each other's shrink loops; same numbers either way) */
     int32_t stats_lags;        /* L >= 0: lags of the running autocovariance sums (see stats_dev) */
-    double *stats_dev;         /* NULL or [gsss_stats_rows(d, stats_modes, stats_lags)][n_chains]: running statistics of the RETAINED
+    double *stats_dev;         /* NULL or [gsss_stats_rows(d, stats_modes, stats_lags, stats_flags)][n_chains]: running statistics of the RETAINED
                                   series (every thin-th state, whether or not samples_dev is given), ADDED to across calls, so that
                                   moments, geodesic step, hopping frequency, mode occupancy and the autocorrelation / IAT / ESS of one
                                   projection need no stored draws (geosss/utils.py:96-134, sphere.py:64-68, scripts/bingham.py:23-25,
-                                  scripts/vMF_diagnostics.py:335-342).  Zero it before the first call.  Rows, with T = d (d + 1) / 2,
-                                  K = stats_modes, L = stats_lags:
+                                  scripts/vMF_diagnostics.py:335-342).  Zero it before the first call.  Rows, with T = d (d + 1) / 2 (0 with
+                                  GSSS_STATS_NO_SECOND_MOMENT), K = stats_modes, L = stats_lags:
                                     0                count n of retained draws
                                     1 .. d           the last retained draw
                                     .. + d           sum of the draws
@@ -180,7 +183,9 @@ typedef struct gsss_run_args {
                                     .. + L           sum_t p_t p_{t-l}, l = 1 .. L
                                     .. + L           ring of the last L values of p (slot t mod L)
                                     .. + L           the first L values of p
-                                  Lane-per-chain kernels only (d <= 10 exact, the lane fast kernels); GSSS_E_UNSUPPORTED otherwise */
+                                  Every slice-sampler kernel family accumulates them (lane, lane-group and cooperative layouts;
+                                  the group layouts form the second moments through cross-lane reads: d <= 64 with them,
+                                  any d with GSSS_STATS_NO_SECOND_MOMENT); GSSS_E_UNSUPPORTED for registration targets */
     const double *stats_dirs_dev; /* [2 + stats_modes][d]: w, h, then the mode directions; required with stats_dev */
     int32_t stats_modes;       /* K >= 0 */
     int32_t n_leapfrog;        /* GSSS_HMC: leapfrog steps per proposal (SphericalHMC(n_steps=10), mcmc.py:243) */
@@ -203,6 +208,14 @@ typedef struct gsss_run_args {
                                   only advances on RWMH proposals (mcmc.py:108-115 called from :226-228), so the adaptation of a chain
                                   ends after `burnin` RWMH proposals, not after `burnin` steps; adapt_steps is unused */
     int64_t *n_rwmh_dev;       /* [n_chains] or NULL; RWMH proposals are ADDED (rwmh_counter; indep_counter = steps - that) */
+    /* ABI 9 */
+    double *momenta_samples_dev; /* GSSS_HMC: NULL or the momentum half of the state after every thin-th step, laid out like
+                                    samples_dev (same samples_chain_rows): SphericalHMC.sample(return_momenta=True), mcmc.py:321-332 */
+    double *stepsize_trace_dev;  /* GSSS_RWMH / GSSS_INDEP / GSSS_MIX: NULL or [n_steps][n_chains]; entry [s][c] = the stepsize of chain c
+                                    after step s if that step made a RWMH proposal, else NaN
+                                    (MixtureRWMHIndependenceSampler.rwmh_stepsize_vals, mcmc.py:201, 228) */
+    int32_t stats_flags;         /* GSSS_STATS_* bits; changes the row layout of stats_dev (gsss_stats_rows takes the same flags) */
+    int32_t reserved0;
 } gsss_run_args;
 
 int gsss_abi_version(void);
@@ -228,8 +241,8 @@ int gsss_gradient(const gsss_target *t, const double *x_dev, int64_t n, double *
 /* The sampler (see gsss_run_args). */
 int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);
 
-/* Number of rows of gsss_run_args.stats_dev for dimension d, K modes and L lags (< 0: bad argument). */
-int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags);
+/* Number of rows of gsss_run_args.stats_dev for dimension d, K modes, L lags and the GSSS_STATS_* flags (< 0: bad argument). */
+int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags, int32_t flags);
 
 /* 1 if gsss_run accepts `mode` for this target's shape (fast mode is built for the shapes listed in
  * geosss_amd/csrc/gsss_fast_*.hip), else 0. */

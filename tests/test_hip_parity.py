@@ -41,27 +41,42 @@ def test_logprob_kat(gs, name):
     assert isinstance(one, float) and abs(one - want[3]) / max(1.0, abs(want[3])) < TOL
 
 
+# the kernel families of packed fast mode -- what bench.py times (gsss_fast_*.hip pick one per shape)
+PACKED_FAST_KERNELS = ("screened_kernel", "curvespec_kernel", "coopfast_kernel")
+
+
+def _packed_kernel(s):
+    """Name of the kernel a packed fast-mode launch of sampler `s` runs (what a rocprofv3 trace shows)."""
+    return s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0, 1).decode()
+
+
 def _traj_params():
     out = []
     for name in trajectory_names("shrink") + trajectory_names("reject"):
         d = int(golden(name + ".npz")["x0"].shape[0])
         z = golden(name + ".npz")
         for v in variants_for(d):
-            out.append((name, v, "exact"))
+            out.append((name, v, "exact", "auto"))
+        out.append((name, 0, "exact", "packed"))
         if "fast" in modes_for(z):
-            out.append((name, 0, "fast"))
+            out.append((name, 0, "fast", "auto"))
+            out.append((name, 0, "fast", "packed"))
     return out
 
 
-@pytest.mark.parametrize("name,variant,mode", _traj_params())
-def test_trajectory_replay(gs, name, variant, mode):
+@pytest.mark.parametrize("name,variant,mode,placement", _traj_params())
+def test_trajectory_replay(gs, name, variant, mode, placement):
     """Replaying the reference's recorded draws through the HIP kernel reproduces the
-    reference chain: every state (1e-10), tries per chain and n_reject (exact)."""
+    reference chain: every state (1e-10), tries per chain and n_reject (exact).  placement 'auto' spreads a
+    one-chain ensemble (one wavefront per chain); 'packed' runs the throughput kernels bench.py times
+    (screened_kernel / curvespec_kernel / coopfast_kernel with their replay draw source)."""
     z = golden(name + ".npz")
     pdf = product_target(z)
     cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
-    s = cls(pdf, z["x0"], seed=1, variant=variant, mode=mode)
+    s = cls(pdf, z["x0"], seed=1, variant=variant, mode=mode, placement=placement)
     assert s.mode == mode
+    if mode == "fast" and placement == "packed":
+        assert _packed_kernel(s).startswith(PACKED_FAST_KERNELS), _packed_kernel(s)
     n = len(z["states"]) - 1
     kept = s.advance(n, thin=1, replay=z["draws"][None])
     got = kept[:, :, 0].cpu().numpy()
@@ -73,17 +88,22 @@ def test_trajectory_replay(gs, name, variant, mode):
 
 
 def _tf_params():
-    return [(n, m) for n in trajectory_names("shrink") for m in modes_for(golden(n + ".npz"))]
+    return [(n, m, p) for n in trajectory_names("shrink") + trajectory_names("reject") for m in modes_for(golden(n + ".npz"))
+            for p in ("auto", "packed")]
 
 
-@pytest.mark.parametrize("name,mode", _tf_params())
-def test_trajectory_teacher_forced(gs, name, mode):
+@pytest.mark.parametrize("name,mode,placement", _tf_params())
+def test_trajectory_teacher_forced(gs, name, mode, placement):
     """All steps of the reference chain at once: chain i starts from reference state i and
-    replays the draws of step i; compares the next state and the number of tries."""
+    replays the draws of step i; compares the next state and the number of tries.  Both placements: the
+    packed leg runs every recorded transition of the reference through the throughput kernels."""
     z = golden(name + ".npz")
     pdf = product_target(z)
     states = z["states"]
-    s = gs.ShrinkageSphericalSliceSampler(pdf, states[:-1], seed=1, mode=mode)
+    cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
+    s = cls(pdf, states[:-1], seed=1, mode=mode, placement=placement)
+    if mode == "fast" and placement == "packed":
+        assert _packed_kernel(s).startswith(PACKED_FAST_KERNELS), _packed_kernel(s)
     s.advance(1, replay=pad_replay(z["draws"], z["step_draw_offset"]))
     assert np.all(s.errors == 0)
     assert np.max(np.abs(s.state - states[1:])) < TOL
@@ -746,3 +766,40 @@ def test_replay_stream_too_short_is_flagged(gs, mode, placement):
     assert t.errors[0] & 4
     with pytest.raises(gs._lib.GsssError):
         t._check_errors()
+
+
+# ------------------------------------------------------------------ round 3: sliced launches
+
+
+@pytest.mark.parametrize("name,n_chains", [("curve_d10_kappa800", 60_000), ("curve_d24_kappa800", 60_000), ("curve_d50_kappa800", 40_000),
+                                           ("curve_d100_kappa800", 20_000), ("curve_d200_kappa800", 10_000)])
+@pytest.mark.parametrize("sampler", ["shrink", "reject"])
+def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sampler, monkeypatch):
+    """Ensembles whose chunks do not fit the chip at once are launched SLICED (one workgroup per (chunk, step slice), tickets,
+    hand-over of the chunk's state through HBM: SliceSched, gsss_device.h).  Slice boundaries sit where the kernels refresh their
+    carried quantities anyway, so every output -- states, retained rows, tries, rejections, error flags -- equals the unsliced
+    launch BIT FOR BIT, for any slice length, any step offset and any split of the steps over launches; a chain that stops
+    with an error flag in one slice stays stopped in the next."""
+    import torch
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=41).T
+    cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    steps = (150, 75) if sampler == "shrink" else (130,)
+    max_tries = 34 if sampler == "shrink" else 1 << 20     # shrink: some chains run into max_tries (kappa = 800 needs ~7 a step)
+    out = {}
+    for label, env in (("whole", "0"), ("s64", "64"), ("s128", "128")):
+        monkeypatch.setenv("GSSS_SLICE_STEPS", env)
+        s = cls(pdf, x0, seed=5, mode="fast", placement="packed", step_offset=37, max_tries=max_tries)
+        assert _packed_kernel(s).startswith("curvespec_kernel")
+        kept = [s.advance(m, thin=7) for m in steps]
+        out[label] = (s.state_device.clone(), torch.cat(kept), s._n_tries.clone(), s._n_reject.clone(), s._err.clone())
+    for label in ("s64", "s128"):
+        for i in range(5):
+            assert torch.equal(out["whole"][i], out[label][i]), (label, i)
+    err = out["whole"][4]
+    if sampler == "shrink":
+        assert 0 < int((err != 0).sum()) < n_chains // 2          # the error path was exercised, most chains are healthy
+    else:
+        assert int((err != 0).sum()) == 0

@@ -210,12 +210,19 @@ def test_bingham_d50_geodesic_step(gs):
 # ------------------------------------------------------------------ running statistics inside the sampler kernels
 
 
-@pytest.mark.parametrize("name,mode,placement,n_chains", [
-    ("vmfmix_readme", "fast", "packed", 3000), ("vmfmix_readme", "fast", "spread", 64), ("vmfmix_readme", "exact", "packed", 500),
-    ("vmfmix_k10_kappa500", "fast", "packed", 1000), ("bingham_d10_vmax30", "fast", "packed", 1500),
-    ("bingham_d10_vmax30", "exact", "packed", 300), ("curve_d10_kappa800", "fast", "packed", 700),
-    ("vmfmix_d4_k4_weighted", "fast", "packed", 900)])
-def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placement, n_chains):
+@pytest.mark.parametrize("name,mode,placement,n_chains,second", [
+    ("vmfmix_readme", "fast", "packed", 3000, None), ("vmfmix_readme", "fast", "spread", 64, None), ("vmfmix_readme", "exact", "packed", 500, None),
+    ("vmfmix_k10_kappa500", "fast", "packed", 1000, None), ("bingham_d10_vmax30", "fast", "packed", 1500, None),
+    ("bingham_d10_vmax30", "exact", "packed", 300, None), ("curve_d10_kappa800", "fast", "packed", 700, None),
+    ("vmfmix_d4_k4_weighted", "fast", "packed", 900, None), ("vmfmix_readme", "fast", "packed", 700, False),
+    # lane-group and cooperative layouts (round 3): the group-speculative curve kernel in each of its group sizes, the
+    # cooperative Bingham / mixture kernels, the exact mode's cooperative layout; second moments through cross-lane reads
+    ("curve_d10_kappa800", "fast", "packed", 333, True), ("curve_d24_kappa800", "fast", "packed", 200, True),
+    ("curve_d50_kappa800", "fast", "packed", 300, None), ("curve_d100_kappa800", "fast", "packed", 100, None),
+    ("curve_d200_kappa800", "fast", "packed", 150, None), ("curve_d200_kappa800", "fast", "spread", 40, None),
+    ("bingham_d50_vmax300", "fast", "packed", 300, None), ("bingham_d50_vmax300", "fast", "packed", 70, True),
+    ("curve_d24_kappa800", "exact", "packed", 100, True), ("curve_d50_kappa800", "exact", "packed", 60, None)])
+def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placement, n_chains, second):
     """The accumulators the kernels keep per chain (gsss_run_args.stats_dev) give the very numbers the reference's
     post-hoc estimators give on the stored draws: moments, geodesic step, hopping frequency, mode occupancy, the
     autocorrelation utils.acf and the IAT heuristic on it -- 1e-12; and feeding them without storing anything
@@ -231,14 +238,18 @@ def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placem
     L, thin, n_keep = 24, 3, 400
     w = np.linspace(1.0, 2.0, d)
     hop = getattr(pdf, "mode", np.eye(d)[1])
-    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=11, mode=mode, placement=placement).enable_stats(lags=L, projection=w, hop=hop)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=11, mode=mode, placement=placement).enable_stats(
+        lags=L, projection=w, hop=hop, second_moment=second)
     s.advance(50)                                                   # burn-in: not part of the statistics
     kept = torch.cat([s.advance(n_keep // 2 * thin, thin=thin), s.advance(n_keep // 2 * thin, thin=thin)])  # two launches
     X = kept.permute(2, 0, 1).contiguous()                          # (chains, draws, dims)
     r = s.stats()
     assert torch.equal(r["n"], torch.full((n_chains,), float(n_keep), dtype=torch.float64, device=X.device))
     assert torch.allclose(r["mean"], X.mean(1), rtol=0, atol=1e-13)
-    assert torch.allclose(r["second_moment"], torch.einsum("cti,ctj->cij", X, X) / n_keep, rtol=0, atol=1e-13)
+    if second is True or (second is None and d <= 16):  # (the d (d + 1) / 2 rows are left out beyond d = 16 unless asked for)
+        assert torch.allclose(r["second_moment"], torch.einsum("cti,ctj->cij", X, X) / n_keep, rtol=0, atol=1e-13)
+    else:
+        assert "second_moment" not in r
     assert torch.allclose(r["geodesic_step"], dg.distance(X[:, 1:], X[:, :-1]).mean(1), rtol=1e-12, atol=1e-14)
     assert torch.allclose(r["hopping_frequency"], dg.hopping_frequency(X, hop), rtol=0, atol=1e-15)
     if isinstance(pdf, gs.MixtureModel):
@@ -249,18 +260,20 @@ def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placem
     assert torch.allclose(r["acf"], dg.acf(P, L + 1), rtol=0, atol=1e-11)
     assert torch.allclose(r["iat"], dg.iat_from_acf(dg.acf(P, L + 1)), rtol=1e-9)
     # the same statistics without storing a draw
-    t = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=11, mode=mode, placement=placement).enable_stats(lags=L, projection=w, hop=hop)
+    t = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=11, mode=mode, placement=placement).enable_stats(
+        lags=L, projection=w, hop=hop, second_moment=second)
     t.advance(50)
     t.advance(n_keep * thin, thin=thin, keep=False)
     assert torch.equal(t._stats["acc"], s._stats["acc"])
 
 
-def test_running_statistics_refused_for_cooperative_layouts(gs):
+def test_running_statistics_second_moment_limit(gs):
+    """d (d + 1) / 2 second-moment rows per chain: accumulated up to d = 64, refused with a message beyond (20 100 rows at d = 200)."""
     from conftest import golden
     from helpers import product_target
-    pdf = product_target(golden("traj_curve_d50_kappa800.npz"))
-    s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere(49, 8, seed=1), seed=1).enable_stats(lags=4)
-    with pytest.raises(ValueError, match="lane-per-chain"):
+    pdf = product_target(golden("traj_curve_d200_kappa800.npz"))
+    s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere(199, 8, seed=1), seed=1).enable_stats(lags=4, second_moment=True)
+    with pytest.raises(ValueError, match="GSSS_STATS_NO_SECOND_MOMENT"):
         s.advance(10, thin=1, keep=False)
 
 
