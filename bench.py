@@ -101,6 +101,48 @@ REFERENCE_NAMES = {"vmfmix_readme": "vmfmix_readme", "vmfmix_k10_kappa500": "vmf
                    "curve_d200": "curve_d200_kappa800"}
 
 
+# What the library's counter-based stream draws per step: said in the bench line so that nobody reads
+# "Philox" as "the reference's arithmetic on another generator"
+STREAM_S2 = ("philox-v2: Philox4x32-10 keyed by (seed, chain, step); S^2: the unit tangent drawn as ONE angle (32 bit) instead of "
+             "three projected normals, theta0 32 bit, threshold and try uniforms 53 bit")
+STREAM_D = ("philox-v2: Philox4x32-10 keyed by (seed, chain, step); d normals per step by single-precision Box-Muller from 32-bit "
+            "words (they only set the tangent's direction), threshold / theta0 / try uniforms 53 bit")
+
+
+def stream_description(d):
+    return STREAM_S2 if d == 3 else STREAM_D
+
+
+def issue_counters(workload, n, S, thin, mode):
+    """Issue-side counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/pmc_traffic.py), quoted only when this run's launch has the profiled shape: how busy the vector pipes were, how many
+    wavefronts were resident, and the FP64 flops the kernel actually ISSUED against the FP64 peak."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))[workload]
+    except (OSError, KeyError, ValueError):
+        return {}
+    shape = rec.get("launch", {})
+    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode")) != (n, S, thin, mode):
+        return {}
+    return dict(rec.get("issue", {}))
+
+
+def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms):
+    """Delivered-work figure: the FP64 flops of the ALL-DOUBLE restricted-form algorithm whose decisions the kernel reproduces
+    (algorithmic_flops) over the kernel time and the FP64 vector peak.  NOT a hardware utilisation: most per-try flops are
+    executed in single precision; `fp64_issued_frac` and `valu_busy` are the hardware's own counters."""
+    flops = algorithmic_flops(name, d, tps)
+    out = {"bound": "fp64_valu", "achieved": flops * n * S / (kern_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+           "frac": flops * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "flops_per_chain_step": flops,
+           "meaning": "algorithmic FP64 flops of the all-double algorithm / kernel time / FP64 vector peak: delivered work, not "
+                      "hardware utilisation (see fp64_issued_frac, valu_busy)"}
+    iss = issue_counters(name, n, S, thin, mode)
+    for k in ("fp64_issued_frac", "valu_busy", "resident_waves_per_simd", "valu_insts_per_chain_step", "lane_activity"):
+        out[k] = iss.get(k)
+    out["counters_source"] = iss.get("source")
+    return out
+
+
 def reference_timing(workload):
     """What the reference itself ran at in the build container (tests/golden/cpu_reference_timing.json,
     written by tests/golden/make_golden.py timing); it cannot run on the GPU box."""
@@ -108,7 +150,8 @@ def reference_timing(workload):
         t = json.load(open(os.path.join(ROOT, "tests", "golden", "cpu_reference_timing.json")))
         r = t["targets"][REFERENCE_NAMES[workload]]
         return {"steps_per_s_1_core": r["steps_per_s_1_process"], "steps_per_s_all_cores": r["steps_per_s_aggregate_all_cores"],
-                "cores": t["host"]["cores"], "cpu": t["host"]["cpu"], "where": "build container, geosss itself"}
+                "cores": t["host"]["cores"], "cpu": t["host"]["cpu"], "where": "build container, geosss itself",
+                "measured": "build container, not this run (the reference's files cannot travel to the GPU box)"}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -162,16 +205,18 @@ def numpy_port_baseline(workload, cores, n_steps=400):
             "sample": f"{n_steps} steps per chain, one chain per process"}
 
 
-def ess_per_sec(gs, sampler, pdf, steps_per_sec_total, n_steps=4000, thin=4, lags=48):
+def ess_per_sec(gs, sampler, pdf, steps_per_sec_total, n_steps=4000, thin=4, lags=64):
     """Effective samples per second (secondary metric) of the WHOLE ensemble of the timed run: the sampler kernels
     accumulate the lag sums of the first coordinate per chain (gsss_run_args.stats_dev; no draws are stored -- at
     10^6 chains x 4000 steps they would be 96 GB) and the reference's own estimator (utils.acf + the IAT heuristic,
     geosss/utils.py:96-134, on the series thinned by `thin`) gives n_eff per chain; plus the mode occupancy."""
-    sampler.enable_stats(lags=lags)
+    sampler.enable_stats(lags=lags, second_moment=False)
     sampler.advance(n_steps, thin=thin, keep=False)
     r = sampler.stats()
     rel = float((r["n_eff"] / r["n"]).mean().item()) / thin        # effective draws per chain-step
+    trunc = float(r["iat_truncated"].double().mean().item())
     out = {"ess_per_step": rel, "ess_per_sec": rel * steps_per_sec_total,
+           "iat_truncated_frac": trunc,  # chains whose pair sums never went negative within the lags: their IAT is a lower bound
            "estimator": f"geosss IAT heuristic on the running autocorrelation of the first coordinate (lags <= {lags} x {thin} "
                         f"steps), all {sampler.n_chains} chains x {n_steps} steps, no stored draws"}
     if "mode_occupancy" in r:
@@ -216,7 +261,7 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def time_config(gs, torch, name, n, S, seed=3521):
+def time_config(gs, torch, name, n, S, seed=3521, ess=True):
     """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload."""
     pdf, d = make_target(gs, name)
     x0 = gs.sample_sphere_device(d - 1, n, seed=0)
@@ -244,19 +289,19 @@ def time_config(gs, torch, name, n, S, seed=3521):
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
     bytes_launch = hbm_bytes_per_step(d, thin, S) * n * S
-    flops = algorithmic_flops(name, d, tps)
     traffic, src = measured_traffic(name, n, S, thin, s.mode)
+    value = n * S * reps / dt
+    # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
+    ess_out = ess_per_sec(gs, s, pdf, value, n_steps=2000, thin=8 if name.startswith("bingham") else 4) if ess else None
     return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}",
-            "value": n * S * reps / dt, "unit": "chain-steps/s", "launches": reps, "mode": s.mode,
+            "stream": stream_description(d),
+            "value": value, "unit": "chain-steps/s", "launches": reps, "mode": s.mode, "ess": ess_out,
             "kernel": lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(),
             "kernel_ms": kern_ms, "tries_per_step": tps, "chains_in_error": int((s._err != 0).sum().item()),
             "roofline": {"bound": "hbm", "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": src},
-            "roofline_valu": {"bound": "fp64_valu", "achieved": flops * n * S / (kern_ms * 1e-3) / 1e12,
-                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": flops * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                              "flops_per_chain_step": flops}}
+            "roofline_valu": roofline_valu(name, d, tps, n, S, thin, s.mode, kern_ms)}
 
 
 def main(argv=None):
@@ -287,6 +332,14 @@ def main(argv=None):
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n")
         return 2
+    backend = os.environ.get("GSSS_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl":
+        import torch  # (device_count() does not initialise the GPU)
+        if torch.cuda.device_count() < world:
+            if rank == 0:
+                sys.stderr.write(f"bench.py: --gpus {world} over RCCL needs {world} visible GPUs, this node shows "
+                                 f"{torch.cuda.device_count()} (one rank per GPU; GSSS_BENCH_BACKEND=gloo rehearses the ranks on fewer)\n")
+            return 3
 
     import geosss_amd as gs                          # imports torch; does not initialise the GPU
     pdf, d = make_target(gs, args.workload)
@@ -300,7 +353,6 @@ def main(argv=None):
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # one process per GPU; GSSS_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the
     # multi-rank code path on a single-GPU box (RCCL refuses two ranks on one device)
-    backend = os.environ.get("GSSS_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     if world > 1:
@@ -361,6 +413,14 @@ def main(argv=None):
     assert final.shape[1] == n * world
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:  # per-rank kernel time and this rank's own wall clock: imbalance between GPUs shows in the line
+        mine = torch.tensor([kern_ms, (time.perf_counter() - t0) * 1e3], dtype=torch.float64, device="cuda")
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank = torch.stack(per_rank).cpu().numpy()
+        rccl["kernel_ms_per_rank"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()),
+                                      "all": [float(v) for v in per_rank[:, 0]]}
+        rccl["wall_ms_per_rank"] = {"min": float(per_rank[:, 1].min()), "max": float(per_rank[:, 1].max())}
     tries = int(sampler._n_tries.sum().item()) - tries0
     bad = int((sampler._err != 0).sum().item())
     chain_steps = n * S * args.steps
@@ -376,14 +436,14 @@ def main(argv=None):
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
-        flops_step = algorithmic_flops(args.workload, d, tries / total_steps)
         traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode)
         out = {
             "metric": "mcmc_chain_steps_per_sec", "value": value, "unit": "chain-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: shrinkage slice sampler, {n} chains/GPU x {S} transitions per "
-                                   "launch, thin=%d, Philox4x32-10 stream" % thin,
+                                   "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
+                       "stream": stream_description(d),
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S,
                        "mode": sampler.mode,
                        "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
@@ -396,10 +456,7 @@ def main(argv=None):
                          "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                  "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
                                  "issue (see roofline_valu and DESIGN.md)"},
-            "roofline_valu": {"bound": "fp64_valu", "achieved": flops_step * n * S / (kern_ms * 1e-3) / 1e12,
-                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": flops_step * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                              "flops_per_chain_step": flops_step},
+            "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms),
         }
         if world == 1 and not args.no_ess:
             out["ess"] = ess_per_sec(gs, sampler, pdf, value)

@@ -81,6 +81,61 @@ __device__ __forceinline__ bool curvespec_decide(const FastCurve<1, NK> &scl, co
     return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
 }
 
+// The same decision taken by the GROUP (round 3): lane g evaluates segments g, g + L, ... at theta = 0 and at theta, a DPP
+// butterfly over the group picks the first segment of maximal clipped value for each -- (value, index) is totally ordered
+// (larger value first, then smaller index), so the winner is the one the sequential scan keeps, and the comparison at the
+// end is formed from the same bits.  An undecided try costs 3 rolled iterations (NK = 10, L = 4) instead of 9 with the other
+// lanes of the wavefront idle: 0.03 undecided tries per chain-step at kappa = 800 were ~15 % of the d = 10 kernel.
+// Every lane of the group calls it (same theta); every lane returns the same answer.
+template <int L, int NK>
+__device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &scl, const double *coef, const fm::Tables &tab, double theta,
+                                                    double u_thr, int g)
+{
+    double sn, cs;
+    fm::sincos_tab(theta, tab, sn, cs);
+    double best0 = -INFINITY, dot0 = 0.0, best1 = -INFINITY, dot1 = 0.0;
+    int idx0 = NK, idx1 = NK;
+#pragma unroll 1
+    for (int gg = g; gg + 1 < NK; gg += L) {
+        const double cxa = coef[gg], cua = coef[NK + gg], cxb = coef[gg + 1], cub = coef[NK + gg + 1];
+        const double ay0 = fma(1.0, cxa, 0.0 * cua), by0 = fma(1.0, cxb, 0.0 * cub);
+        const double ay1 = fma(cs, cxa, sn * cua), by1 = fma(cs, cxb, sn * cub);
+        double xc, xy;
+        scl.segment_value(gg, ay0, by0, xc, xy);
+        if (xc > best0) {
+            best0 = xc;
+            dot0 = xy;
+            idx0 = gg;
+        }
+        scl.segment_value(gg, ay1, by1, xc, xy);
+        if (xc > best1) {
+            best1 = xc;
+            dot1 = xy;
+            idx1 = gg;
+        }
+    }
+    auto merge = [](double &xc, double &xy, int &idx, double oxc, double oxy, int oidx) {
+        const bool take = oxc > xc || (oxc == xc && oidx < idx);
+        xc = take ? oxc : xc;
+        xy = take ? oxy : xy;
+        idx = take ? oidx : idx;
+    };
+#define GSSS_CS_STAGE(CTRL)                                                                             \
+    do {                                                                                                \
+        const double o0 = dpp_move<CTRL>(best0), p0 = dpp_move<CTRL>(dot0), o1 = dpp_move<CTRL>(best1), \
+                     p1 = dpp_move<CTRL>(dot1);                                                         \
+        const int i0 = dpp_move<CTRL>(idx0), i1 = dpp_move<CTRL>(idx1);                                 \
+        merge(best0, dot0, idx0, o0, p0, i0);                                                           \
+        merge(best1, dot1, idx1, o1, p1, i1);                                                           \
+    } while (0)
+    GSSS_CS_STAGE(kDppXor1);
+    GSSS_CS_STAGE(kDppXor2);
+    if (L >= 8) GSSS_CS_STAGE(kDppHalfMirror);
+    if (L >= 16) GSSS_CS_STAGE(kDppMirror);
+#undef GSSS_CS_STAGE
+    return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
+}
+
 template <int L, int Q, int NK, bool REPLAY, bool STATS = false>
 __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
@@ -344,7 +399,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
             lo = 0.0;             // mcmc.py:367
             hi = kTwoPi;
         }
-        auto decide = [&](double theta) -> bool { return curvespec_decide<NK>(scl, coef, tab, theta, u_thr); };
+        auto decide = [&](double theta) -> bool { return curvespec_decide_group<L, NK>(scl, coef, tab, theta, u_thr, g); };
 
         // ---------------- batches of L speculative tries
         bool done = !alive, accepted = false;
@@ -401,14 +456,19 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES :
             const float gap = my_b - q[2 * NK];
             int verdict = mine ? (gap < -q[2 * NK + 1] ? -1 : (gap > q[2 * NK + 1] ? 1 : 0)) : -1;
             // first try of the group that is not certainly rejected; an undecided one is decided in double precision by its lane
+            // (the whole group takes that decision: curvespec_decide_group)
             int T = L;
             for (;;) {
                 const unsigned long long open = __ballot(verdict >= 0);
                 const unsigned gm = (unsigned)(open >> base) & ((1u << L) - 1u);
                 T = gm ? __builtin_ctz(gm) : L;
                 const bool need = g == T && verdict == 0;
-                if (!__any(need)) break;
-                if (need) verdict = decide(my_theta) ? 1 : -1;
+                const unsigned long long needs = __ballot(need);
+                if (needs == 0ull) break;
+                if (((unsigned)(needs >> base) & ((1u << L) - 1u)) != 0u) {  // this group's first open try is undecided
+                    const bool acc = decide(__shfl(my_theta, base + T));
+                    if (need) verdict = acc ? 1 : -1;
+                }
             }
             const double th_T = __shfl(my_theta, base + (T < L ? T : 0));
             const float b_T = __shfl(my_b, base + (T < L ? T : 0));

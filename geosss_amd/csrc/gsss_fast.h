@@ -276,8 +276,8 @@ struct FastCurve {
     {
         return level(cf, c, s);
     }
-    // one segment (a, b) of the curve given a.y and b.y: keeps the first maximum of the clipped y . nearest
-    __device__ __forceinline__ void segment(int g, double ay, double by, double &best, double &best_dot) const
+    // one segment (a, b) of the curve given a.y and b.y: y . nearest (xy) and its clipped value (xc; -inf for a padding segment)
+    __device__ __forceinline__ void segment_value(int g, double ay, double by, double &xc, double &xy) const
     {
         const double ct = seg[4 * g], st = seg[4 * g + 1], rden = seg[4 * g + 2];
         const double A = ay * st;
@@ -288,9 +288,15 @@ struct FastCurve {
         const bool at_a = B < 0.0 || (B == 0.0 && A >= 0.0);
         const bool at_b = A * rh < ct;
         const double num = at_a ? st * ay : (at_b ? st * by : inner);
-        const double xy = num * rden;
-        const double xc = fmin(fmax(xy, -1.0), 1.0);
-        if (g < nseg && xc > best) {
+        xy = num * rden;
+        xc = g < nseg ? fmin(fmax(xy, -1.0), 1.0) : -INFINITY;
+    }
+    // keeps the first maximum of the clipped y . nearest
+    __device__ __forceinline__ void segment(int g, double ay, double by, double &best, double &best_dot) const
+    {
+        double xc, xy;
+        segment_value(g, ay, by, xc, xy);
+        if (xc > best) {
             best = xc;
             best_dot = xy;
         }

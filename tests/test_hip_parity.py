@@ -787,7 +787,7 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
     x0 = gs.sample_sphere_device(d - 1, n_chains, seed=41).T
     cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
     steps = (150, 75) if sampler == "shrink" else (130,)
-    max_tries = 34 if sampler == "shrink" else 1 << 20     # shrink: some chains run into max_tries (kappa = 800 needs ~7 a step)
+    max_tries = 20 if sampler == "shrink" else 1 << 20     # shrink: some chains run into max_tries (kappa = 800 needs ~7 a step)
     out = {}
     for label, env in (("whole", "0"), ("s64", "64"), ("s128", "128")):
         monkeypatch.setenv("GSSS_SLICE_STEPS", env)
@@ -800,6 +800,6 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
             assert torch.equal(out["whole"][i], out[label][i]), (label, i)
     err = out["whole"][4]
     if sampler == "shrink":
-        assert 0 < int((err != 0).sum()) < n_chains // 2          # the error path was exercised, most chains are healthy
+        assert 0 < int((err != 0).sum()) < n_chains               # stopped chains and healthy ones, both kinds in every slice
     else:
         assert int((err != 0).sum()) == 0

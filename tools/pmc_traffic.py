@@ -49,6 +49,33 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
                "launch": {"chains": cfg.get("chains_per_gpu"), "steps": cfg.get("transitions_per_step"), "thin": thin,
                           "mode": cfg.get("mode")},
                "source": f"profiles/{tag}_{wl}_summary.md (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes)"}
+    # issue side of the same kernel (passes sq1 / sq2 / sq3 of tools/collect_profiles.sh): what bench.py quotes next to
+    # roofline_valu so that the delivered-work fraction is never read as a hardware utilisation
+    sq = collections.defaultdict(list)
+    for sub in ("sq1", "sq2", "sq3"):
+        for f in newest(f"{d}/{sub}/**/*_counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r["Kernel_Name"] == name:
+                    sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    sq = {k: sum(v) / len(v) for k, v in sq.items()}
+    chain_steps = (cfg.get("chains_per_gpu") or 0) * (cfg.get("transitions_per_step") or 0)
+    if sq.get("GRBM_GUI_ACTIVE") and chain_steps:
+        simd_cycles = 1024.0 * sq["GRBM_GUI_ACTIVE"] / 8.0          # 256 CUs x 4 SIMDs x cycles of the launch (GRBM counts per XCD)
+        seconds = None                                               # the kernel's average duration in the kernel-trace run
+        for f in newest(f"{d}/trace/**/*_kernel_stats.csv"):
+            for r in csv.DictReader(open(f)):
+                if r["Name"] == name:
+                    seconds = float(r["AverageNs"]) * 1e-9
+        seconds = seconds or sq["GRBM_GUI_ACTIVE"] / 8.0 / 2.4e9
+        out[wl]["issue"] = {
+            "valu_insts_per_chain_step": sq.get("SQ_INSTS_VALU", 0.0) / chain_steps,
+            "valu_busy": 4.0 * sq.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles,
+            "resident_waves_per_simd": 4.0 * sq.get("SQ_WAVE_CYCLES", 0.0) / simd_cycles,
+            "lane_activity": sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / 64.0 / max(1.0, sq.get("SQ_INSTS_VALU", 0.0)),
+            "fp64_flops_issued_per_chain_step": 64.0 * sq.get("SQ_INSTS_VALU_FLOPS_FP64", 0.0) / chain_steps,
+            "fp64_issued_frac": 64.0 * sq.get("SQ_INSTS_VALU_FLOPS_FP64", 0.0) / seconds / 78.6e12,
+            "lds_bank_conflict_cycles_per_lds_inst": sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, sq.get("SQ_INSTS_LDS", 0.0)),
+            "source": f"profiles/{tag}_{wl}_summary.md (SQ_* / GRBM_GUI_ACTIVE, rocprofv3 --pmc, separate passes)"}
     shutil.copy(os.path.join(d, "summary.md"), os.path.join(ROOT, "profiles", f"{tag}_{wl}_summary.md"))
     for f in newest(f"{d}/trace/**/*_kernel_stats.csv"):
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
