@@ -24,8 +24,27 @@ CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contra
 CXXFLAGS += os.environ.get("GSSS_HIPCC_FLAGS", "").split()
 # Per-source flags.  The group-speculative curve kernel keeps ~25 loop-invariant constants (polynomial coefficients, LDS
 # offsets) in vector registers for the whole launch when MachineLICM hoists their moves out of the step loop: without it the
-# kernel fits three wavefronts per SIMD without spilling (measured: 156 against 168 + 8 spilled registers).
-SOURCE_FLAGS = {"gsss_fast_curvespec.hip": ["-mllvm", "-disable-machine-licm"]}
+# kernel fits three wavefronts per SIMD without spilling (measured: 156 against 168 + 8 spilled registers).  The option is an
+# internal LLVM one: it is probed once on an empty translation unit and left out if this compiler does not know it (the
+# kernels then spill -- tests/test_abi.py::test_group_kernels_do_not_spill says so instead of a silent 30 GB of scratch traffic).
+OPTIONAL_SOURCE_FLAGS = {"gsss_fast_curvespec.hip": ["-mllvm", "-disable-machine-licm"]}
+_flag_ok = {}
+
+
+def flag_supported(flags):
+    key = tuple(flags)
+    if key not in _flag_ok:
+        r = subprocess.run([hipcc(), f"--offload-arch={ARCH}", "--cuda-device-only", *flags, "-x", "hip", "-c", "-", "-o", os.devnull],
+                           input="", capture_output=True, text=True)
+        _flag_ok[key] = r.returncode == 0
+        if not _flag_ok[key]:
+            sys.stderr.write(f"geosss_amd.build: {' '.join(flags)} is not accepted by this hipcc, building without it\n")
+    return _flag_ok[key]
+
+
+def source_flags(src):
+    flags = OPTIONAL_SOURCE_FLAGS.get(src, [])
+    return flags if flags and flag_supported(flags) else []
 
 
 def hipcc():
@@ -46,12 +65,12 @@ def headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def compile_one(src, force, extra):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def compile_one(src, force, extra, obj_dir=OBJ):
+    obj = os.path.join(obj_dir, src[:-4] + ".o")
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), headers_mtime()):
         return obj, False
-    cmd = [hipcc(), *CXXFLAGS, *SOURCE_FLAGS.get(src, []), *extra, "-c", path, "-o", obj]
+    cmd = [hipcc(), *CXXFLAGS, *source_flags(src), *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -63,24 +82,43 @@ def compile_one(src, force, extra):
 def build(force=False, jobs=None, extra=(), verbose=True, out=None):
     """`out`: write the library (and its objects) under another name -- side-by-side builds for A/B timing
     (load one with GSSS_HIP_LIB=<path>)."""
-    global OBJ, LIB
+    lib, obj_dir = LIB, OBJ
     if out:
-        LIB = os.path.abspath(out)
-        OBJ = os.path.join(CSRC, "_obj_" + os.path.splitext(os.path.basename(LIB))[0])
-    os.makedirs(OBJ, exist_ok=True)
+        lib = os.path.abspath(out)
+        obj_dir = os.path.join(CSRC, "_obj_" + os.path.splitext(os.path.basename(lib))[0])
+    os.makedirs(obj_dir, exist_ok=True)
     srcs = sources()
     jobs = jobs or min(len(srcs), os.cpu_count() or 1)
     with cf.ThreadPoolExecutor(jobs) as ex:
-        res = list(ex.map(lambda s: compile_one(s, force, list(extra)), srcs))
+        res = list(ex.map(lambda s: compile_one(s, force, list(extra), obj_dir), srcs))
     objs = [o for o, _ in res]
-    if any(changed for _, changed in res) or not os.path.exists(LIB):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if any(changed for _, changed in res) or not os.path.exists(lib):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
         subprocess.check_call(cmd)
         if verbose:
-            print(f"linked {LIB}")
+            print(f"linked {lib}")
     elif verbose:
-        print(f"{LIB} is up to date")
-    return LIB
+        print(f"{lib} is up to date")
+    return lib
+
+
+def resource_usage(src, extra=()):
+    """hipcc's -Rpass-analysis=kernel-resource-usage remarks of one translation unit (device code only, nothing written):
+    {mangled kernel name: {"vgprs", "sgprs", "scratch", "occupancy", "lds"}}."""
+    import re
+    cmd = [hipcc(), *CXXFLAGS, *source_flags(src), *extra, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c",
+           os.path.join(CSRC, src), "-o", os.devnull]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-2000:]}")
+    out = {}
+    for blk in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
+        def g(key):
+            m = re.search(key + r": (\d+)", blk)
+            return int(m.group(1)) if m else None
+        out[blk.split()[0]] = {"vgprs": g("VGPRs"), "sgprs": g("TotalSGPRs"), "scratch": g(r"ScratchSize \[bytes/lane\]"),
+                               "occupancy": g(r"Occupancy \[waves/SIMD\]"), "lds": g(r"LDS Size \[bytes/block\]")}
+    return out
 
 
 if __name__ == "__main__":

@@ -137,7 +137,7 @@ __device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &s
 }
 
 template <int L, int Q, int NK, bool REPLAY, bool STATS = false>
-__global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10) ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
     using V = CoopVec<L, 4 * Q>;
     using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level

@@ -64,10 +64,18 @@ def seed_to_key(seed):
     elif isinstance(seed, np.random.SeedSequence):
         w = seed.generate_state(2, np.uint32)
     elif isinstance(seed, (np.random.Generator, np.random.BitGenerator)):
-        # the key is drawn from a COPY: the caller's generator (kept as sampler.rng) is not advanced
-        g = copy.deepcopy(seed)
-        g = g if isinstance(g, np.random.Generator) else np.random.Generator(g)
-        w = g.integers(0, 2**32, size=2, dtype=np.uint64)
+        # The reference shares the caller's generator (default_rng(gen) returns it, mcmc.py:45), so two samplers built from one
+        # generator draw different numbers.  Here every construction SPAWNS a child of the generator's seed sequence and keys
+        # the Philox stream from it: successive samplers get different keys, the caller's stream position is not touched
+        # (sampler.rng stays where it was).  A generator without a seed sequence (restored from a state) has nothing to spawn
+        # from: the key is drawn from the generator itself, which advances it -- as round 1 did.
+        bg = seed.bit_generator if isinstance(seed, np.random.Generator) else seed
+        ss = getattr(bg, "seed_seq", None)
+        if isinstance(ss, np.random.SeedSequence):
+            w = ss.spawn(1)[0].generate_state(2, np.uint32)
+        else:
+            g = seed if isinstance(seed, np.random.Generator) else np.random.Generator(seed)
+            w = g.integers(0, 2**32, size=2, dtype=np.uint64)
     else:
         w = np.random.SeedSequence(seed).generate_state(2, np.uint32)
     return int(w[0]) | (int(w[1]) << 32)
@@ -374,6 +382,12 @@ class RejectionSphericalSliceSampler:
     def _launch_extra(self, a, n_steps):
         """Hook for samplers with further launch arguments."""
 
+    _sample_buffer = None
+
+    def _begin_sample_buffer(self, out):
+        """sample() has allocated its (chains, draws, dims) buffer and filled row 0; the retained rows follow."""
+        self._sample_buffer = out
+
     def advance(self, n_steps, *, thin=None, out=None, replay=None, chain_major=False, row0=0, keep=True):
         """Advance every chain by n_steps transitions on the GPU (asynchronously).
 
@@ -479,8 +493,12 @@ class RejectionSphericalSliceSampler:
         # the kernels write straight into the reference's (chains, draws, dims) order
         out = torch.empty((self.n_chains, n_rows, self.d), dtype=torch.float64, device=self._tdev)
         out[:, 0, :] = self.state_rows()
-        if n_rows > 1:
-            self.advance((n_rows - 1) * thin, thin=thin, out=out, chain_major=True, row0=1)
+        self._begin_sample_buffer(out)     # (samplers that keep further per-draw rows lay them out like `out`: _launch_extra)
+        try:
+            if n_rows > 1:
+                self.advance((n_rows - 1) * thin, thin=thin, out=out, chain_major=True, row0=1)
+        finally:
+            self._sample_buffer = None
         self._account_calls(self._step - steps0)
         self._check_errors()
         self._sync_rng()
@@ -503,11 +521,15 @@ class MetropolisHastings(RejectionSphericalSliceSampler):
     _sampler = _lib.RWMH
     _calls_per_step = 2  # log_prob(proposal) and log_prob(state), mcmc.py:152
 
-    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, **kwargs):
+    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, *, record_stepsize=False, **kwargs):
         if kwargs.get("mode", "exact") not in ("exact", "auto"):
             raise ValueError("RWMH / HMC evaluate log_prob from the point itself: mode='exact'")
         kwargs["mode"] = "exact"
         super().__init__(distribution, initial_state, seed, **kwargs)
+        # stepsize after every RWMH proposal, kept on the device per launch ([steps, chains], NaN where the step proposed
+        # otherwise): 8 bytes per chain-step, so only on request -- or by default for ONE chain of the mixture sampler below
+        self._record_stepsize = bool(record_stepsize)
+        self._stepsize_traces = []
         if not float(stepsize) > 0.0:
             raise AssertionError("stepsize must be positive")  # mcmc.py:98
         self._stepsize = torch.full((self.n_chains,), float(stepsize), dtype=torch.float64, device=self._tdev)
@@ -526,6 +548,19 @@ class MetropolisHastings(RejectionSphericalSliceSampler):
         a.n_reject_dev = None
         a.n_tries_dev = None
         self._counter += n_steps
+        if self._record_stepsize and self._sampler != _lib.HMC and n_steps > 0:
+            trace = torch.full((n_steps, self.n_chains), float("nan"), dtype=torch.float64, device=self._tdev)
+            a.stepsize_trace_dev = trace.data_ptr()
+            self._stepsize_traces.append(trace)
+
+    def stepsize_trace(self):
+        """[steps, chains] CUDA tensor: the stepsize after every recorded step that made a RWMH proposal, NaN for the others
+        (needs record_stepsize=True)."""
+        if not self._stepsize_traces:
+            return torch.empty((0, self.n_chains), dtype=torch.float64, device=self._tdev)
+        if len(self._stepsize_traces) > 1:
+            self._stepsize_traces = [torch.cat(self._stepsize_traces)]
+        return self._stepsize_traces[0]
 
     @property
     def stepsize(self):
@@ -583,12 +618,17 @@ class MixtureRWMHIndependenceSampler(MetropolisHastings):
     proposal (global jumps), geosss/mcmc.py:185-234, many chains.  As in the reference only RWMH proposals adapt the
     stepsize, and the burn-in counter only advances on them: a chain adapts during its first `burnin` RWMH proposals.
     Attributes of the reference: `.alpha`, `.n_accept`, `.rwmh_counter`, `.indep_counter` (totals over chains; per chain:
-    `rwmh_counter_per_chain`); `.rwmh_stepsize_vals` (the stepsize after every RWMH proposal) is not recorded."""
+    `rwmh_counter_per_chain`); `.rwmh_stepsize_vals`: the stepsize after every RWMH proposal (mcmc.py:201, 228) -- a list of
+    floats for one chain as in the reference, a list of per-chain arrays for many; recorded by default for one chain,
+    `record_stepsize=True` for an ensemble (8 bytes per chain-step on the device)."""
 
     _sampler = _lib.MIX
 
-    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, mixing_probability=0.5, **kwargs):
-        super().__init__(distribution, initial_state, seed, stepsize=stepsize, **kwargs)
+    def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, mixing_probability=0.5, *, record_stepsize=None,
+                 **kwargs):
+        one = np.ndim(initial_state) == 1 or len(initial_state) == 1
+        super().__init__(distribution, initial_state, seed, stepsize=stepsize,
+                         record_stepsize=one if record_stepsize is None else record_stepsize, **kwargs)
         self.alpha = float(mixing_probability)
         if not 0.0 <= self.alpha <= 1.0:
             raise ValueError("mixing_probability must lie in [0, 1]")
@@ -613,6 +653,14 @@ class MixtureRWMHIndependenceSampler(MetropolisHastings):
     @property
     def rwmh_counter_per_chain(self):
         return self._n_rwmh.cpu().numpy()
+
+    @property
+    def rwmh_stepsize_vals(self):
+        if not self._record_stepsize:
+            raise ValueError("the stepsizes of an ensemble are recorded on request: record_stepsize=True")
+        t = self.stepsize_trace().cpu().numpy()
+        per_chain = [t[~np.isnan(t[:, c]), c] for c in range(self.n_chains)]
+        return [float(v) for v in per_chain[0]] if self._single else per_chain
 
     @property
     def rwmh_counter(self):
@@ -647,11 +695,15 @@ class SphericalHMC(MetropolisHastings):
         if self.n_steps < 1:
             raise ValueError("n_steps must be >= 1")
         self._momenta = torch.zeros((self.d, self.n_chains), dtype=torch.float64, device=self._tdev)  # mcmc.py:262
+        self._momenta_rows = None
 
     def _launch_extra(self, a, n_steps):
         super()._launch_extra(a, n_steps)
         a.n_leapfrog = self.n_steps
         a.momenta_dev = self._momenta.data_ptr()
+        if self._momenta_rows is not None and self._sample_buffer is not None and a.samples_dev:
+            # the momenta of the retained rows, laid out like the positions' buffer (same shape, same row offsets)
+            a.momenta_samples_dev = self._momenta_rows.data_ptr() + (a.samples_dev - self._sample_buffer.data_ptr())
 
     @property
     def momenta(self):
@@ -678,6 +730,22 @@ class SphericalHMC(MetropolisHastings):
             raise ValueError("the number of chains is fixed at construction")
 
     def sample(self, n_samples, burnin=0, return_momenta=False, return_all_samples=False, *, thin=1, as_tensor=False):
-        if return_momenta:
-            raise NotImplementedError("momenta are not retained per draw; `sampler.momenta` holds the current ones")
-        return super().sample(n_samples, burnin, return_all_samples, thin=thin, as_tensor=as_tensor)
+        """mcmc.py:321-332: the positions, or (positions, momenta) -- the two halves of the reference's [x, v] rows."""
+        if not return_momenta:
+            return super().sample(n_samples, burnin, return_all_samples, thin=thin, as_tensor=as_tensor)
+        if not n_samples > 0:
+            raise AssertionError("n_samples must be positive")
+        b = determine_burnin(n_samples, burnin)
+        n_rows = n_samples + b if return_all_samples else n_samples
+        self._momenta_rows = torch.zeros((self.n_chains, n_rows, self.d), dtype=torch.float64, device=self._tdev)
+        try:
+            x = super().sample(n_samples, burnin, return_all_samples, thin=thin, as_tensor=True)
+            v = self._momenta_rows[0] if self._single else self._momenta_rows
+        finally:
+            self._momenta_rows = None
+        return (x, v) if as_tensor else (x.cpu().numpy(), v.cpu().numpy())
+
+    def _begin_sample_buffer(self, out):
+        super()._begin_sample_buffer(out)
+        if self._momenta_rows is not None:  # row 0: the momenta of the state the retained rows start from (mcmc.py:67, 262)
+            self._momenta_rows[:, 0, :] = self._momenta.T

@@ -83,47 +83,53 @@ def matrix2quat(R):
     return Rotation.from_matrix(np.asarray(R, dtype=np.float64)).as_quat()
 
 
+def _pose_matrix(rotation):
+    """A pose given as a unit quaternion (x, y, z, w) or as a matrix -> the matrix."""
+    rotation = np.asarray(rotation, dtype=np.float64)
+    return quat2matrix(rotation) if rotation.shape[-1] == 4 else rotation
+
+
 class PointCloud:
-    """Weighted point cloud in 2-D or 3-D (pointcloud.py:206-270)."""
+    """Parameter carrier of a weighted cloud of n points in the plane or in space: what the device target is packed from
+    (`positions` (n, m), `weights` (n,)) plus the pose arithmetic the reference's scripts call on it (pointcloud.py:206-270:
+    same constructor, attributes and method names).  `_rows_dropped`: how many trailing rows of a pose matrix do NOT act on the points
+    -- none here, the last one for the projected cloud below."""
+
+    _rows_dropped = 0
 
     def __init__(self, positions, weights=None):
-        if np.ndim(positions) != 2:
-            raise ValueError("Expected rank-2 array")
-        if np.shape(positions)[1] not in (2, 3):
-            raise ValueError("Expected 2d or 3d point cloud")
-        self.positions = np.array(positions, dtype=np.float64)
-        self.weights = np.ones(len(self.positions)) if weights is None else np.array(weights, dtype=np.float64)
+        pts = np.array(positions, dtype=np.float64)
+        if pts.ndim != 2 or pts.shape[1] not in (2, 3):
+            raise ValueError(f"a point cloud is an (n, 2) or (n, 3) array, got shape {pts.shape}")
+        w = np.ones(len(pts)) if weights is None else np.array(weights, dtype=np.float64)
+        if w.shape != (len(pts),):
+            raise ValueError(f"one weight per point: expected {(len(pts),)}, got {w.shape}")
+        self.positions, self.weights = pts, w
 
-    @property
-    def dim(self):
-        return self.positions.shape[1]
-
-    @property
-    def size(self):
-        return self.positions.shape[0]
+    dim = property(lambda self: self.positions.shape[1], doc="dimension of the space the points live in")
+    size = property(lambda self: self.positions.shape[0], doc="number of points")
 
     @property
     def center_of_mass(self):
-        return self.weights @ self.positions / self.weights.sum()
+        return np.average(self.positions, axis=0, weights=self.weights)
 
     def transform_positions(self, rotation, translation=None):
-        rotation = quat2matrix(rotation) if np.shape(rotation)[-1] == 4 else np.asarray(rotation, dtype=np.float64)
-        if translation is None:
-            translation = np.zeros(len(rotation))
-        return self.positions.dot(rotation.T) + translation
+        """The points under the pose: R x_i (+ translation), R a unit quaternion or a matrix."""
+        R = _pose_matrix(rotation)
+        R = R[: len(R) - self._rows_dropped]
+        moved = np.einsum("ij,nj->ni", R, self.positions)
+        return moved if translation is None else moved + np.asarray(translation, dtype=np.float64)
 
     def transform(self, rotation, translation=None):
+        """Moves the stored points."""
         self.positions = self.transform_positions(rotation, translation)
 
 
 class RotationProjection(PointCloud):
-    """Rotation of a 3-D cloud followed by the parallel projection onto the xy plane (pointcloud.py:273-293)."""
+    """A 3-D cloud seen in parallel projection along z after the rotation (pointcloud.py:273-293): only the first two rows of
+    the pose matrix act, the transformed points are 2-D."""
 
-    def transform_positions(self, rotation, translation=None):
-        rotation = quat2matrix(rotation) if np.shape(rotation)[-1] == 4 else np.asarray(rotation, dtype=np.float64)
-        if translation is None:
-            translation = np.zeros(self.dim - 1)
-        return self.positions @ rotation[:-1].T + translation
+    _rows_dropped = 1
 
 
 class GaussianMixtureModel(Distribution):

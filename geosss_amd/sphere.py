@@ -40,26 +40,27 @@ def sample_sphere_device(d, size, seed=0, chain_offset=0, device=None):
     return out
 
 
-def sample_sphere(d=2, size=None, seed=None, device=None, rng="auto"):
+def sample_sphere(d=2, size=None, seed=None, device=None, rng="numpy"):
     """Same call signature as geosss.sphere.sample_sphere (sphere.py:39-50); rows are points.
 
     rng="numpy": the reference's own construction, `radial_projection(default_rng(seed).standard_normal(...))`
     on the host, so that target recipes such as `500 * sample_sphere(2, 10, seed=1234)`
     (scripts/mixture_vMF.py:406-411) or x0 = `sample_sphere(d - 1, seed=1345)` (scripts/curve_vMF.py:577-589)
-    build the very arrays the reference builds.  rng="philox": the device twin (`sample_sphere_device`,
-    the counter-based stream; what 10^6-chain ensembles are initialised with).  rng="auto" (default) is
-    "numpy" up to 10^5 points and "philox" beyond."""
-    if rng not in ("auto", "numpy", "philox"):
-        raise ValueError("rng must be 'auto', 'numpy' or 'philox'")
+    build the very arrays the reference builds -- the default, for every size, so that the points of a (d, seed) call never
+    depend on how many are asked for beyond the prefix rule of numpy's stream.  rng="philox": the device twin
+    (`sample_sphere_device`, the counter-based stream; what 10^6-chain ensembles are initialised with; it needs an explicit
+    seed -- there is no fresh entropy on that path -- and honours `device`)."""
+    if rng not in ("numpy", "philox"):
+        raise ValueError("rng must be 'numpy' or 'philox'")
     n = 1 if size is None else int(size)
-    if rng == "auto":
-        rng = "numpy" if n <= 100_000 else "philox"
+    if rng == "philox" and seed is None:
+        raise ValueError("rng='philox' is a counter-based stream: pass a seed")
     if rng == "numpy":
         g = np.random.default_rng(seed)
         x = g.standard_normal(d + 1) if size is None else g.standard_normal((n, d + 1))
         norm = np.linalg.norm(x, axis=-1) + 1e-100  # sphere.py:14
         return x / norm if x.ndim == 1 else x / norm[:, None]
-    x = sample_sphere_device(d, n, seed=0 if seed is None else seed, device=device).T.contiguous().cpu().numpy()
+    x = sample_sphere_device(d, n, seed=seed, device=device).T.contiguous().cpu().numpy()
     return x[0] if size is None else x
 
 

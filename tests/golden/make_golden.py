@@ -423,10 +423,12 @@ def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10, alp
     s.reset(burnin)
     s.rng = RecordingRNG(seed)
     states, accept, eps, offs = [np.array(x0, dtype=float)], [], [], [0]
+    mom = [np.zeros(d)]                       # SphericalHMC: the momentum half of every row, mcmc.py:262, 321-332
     for _ in range(n_steps):
         n0 = s.n_accept
         y = np.copy(next(s))
         states.append(y[:d])
+        mom.append(y[d:] if kind == "hmc" else np.zeros(d))
         accept.append(s.n_accept - n0)
         eps.append(s.stepsize)
         offs.append(len(s.rng.draws))
@@ -438,6 +440,7 @@ def record_mh(kind, pdf, x0, seed, n_steps, burnin, stepsize, n_leapfrog=10, alp
                stepsize0=np.float64(stepsize), n_leapfrog=np.int64(n_leapfrog), sampler=np.array(kind))
     if kind == "hmc":
         out["momenta"] = np.array(s.state[d:])
+        out["momenta_trace"] = np.array(mom)   # what sample(return_momenta=True) returns next to the positions
     if kind == "mix":
         per_step = np.diff(np.array(offs))
         out.update(use_rwmh=(per_step == d + 3).astype(np.int8), rwmh_counter=np.int64(s.rwmh_counter),

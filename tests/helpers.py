@@ -47,9 +47,7 @@ def pad_replay(draws, offsets):
 
 
 # shapes the GSSS_MODE_FAST kernels are built for (geosss_amd/csrc/gsss_fast_*.hip)
-FAST_VMF = {(3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 6), (3, 8), (3, 10), (4, 4), (5, 5), (10, 3), (10, 5), (10, 10)}
-FAST_BINGHAM = {3, 4, 5, 6, 7, 8, 9, 10}
-FAST_CURVE = {(d, 10) for d in (3, 6, 9, 10, 12, 15, 18, 21, 24)}  # (d, knots)
+FAST_BINGHAM = {3, 4, 5, 6, 7, 8, 9, 10}  # lane kernels; 10 < d <= 128 runs the cooperative one
 
 
 def fast_supported(z, prefix="target_"):

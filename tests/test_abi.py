@@ -38,6 +38,22 @@ def test_struct_layouts_match_header():
         assert fields == [f[0] for f in cls._fields_], cname
 
 
+def test_integration_doc_structs_match_header():
+    """INTEGRATION.md section B shows the ctypes binding a geosss maintainer would add: its two struct snippets list the
+    header's fields, in the header's order, under the header's ABI version (round 2's drifted: ABI 7, a truncated _Desc)."""
+    from geosss_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cls_name, cls in (("_Desc", _lib.TargetDesc), ("_Run", _lib.RunArgs)):
+        start = doc.index(f"class {cls_name}(C.Structure):")
+        block = doc[start: doc.index("\n\n", start)]                      # the class statement up to the next blank line
+        fields = re.findall(r'\("([a-z_0-9A-Z]+)", C\.(c_[a-z0-9_]+)\)', block)
+        assert [f for f, _ in fields] == [f[0] for f in cls._fields_], cls_name
+        import ctypes as C
+        assert [getattr(C, t) for _, t in fields] == [f[1] for f in cls._fields_], cls_name   # (c_int32 IS c_int here)
+    assert f"ABI version {_lib.ABI_VERSION}" in doc and f"(ABI {_lib.ABI_VERSION})" in doc
+    assert not re.search(r"ABI version (?!%d)\d" % _lib.ABI_VERSION, doc)
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
@@ -117,14 +133,18 @@ def test_sample_sphere_is_the_reference_recipe():
 
 
 def test_seed_argument_handling():
-    """Seeds are never silently reinterpreted: a list of seeds is refused for the Philox stream, and a Generator
-    handed over as seed is not advanced by deriving the key from it."""
+    """Seeds are never silently reinterpreted: a list of seeds is refused for the Philox stream; a Generator handed over as
+    seed keeps its stream position, and every sampler built from it gets a key of its own (a spawned child of its seed
+    sequence) -- two samplers from one generator are independent, as in the reference, which shares the generator (mcmc.py:45)."""
     import geosss_amd as gs
     from geosss_amd.mcmc import seed_to_key
     g = np.random.default_rng(5)
     before = g.bit_generator.state
     k1, k2 = seed_to_key(g), seed_to_key(g)
-    assert k1 == k2 and g.bit_generator.state == before
+    assert k1 != k2 and g.bit_generator.state == before
+    h = np.random.default_rng(5)
+    assert (seed_to_key(h), seed_to_key(h)) == (k1, k2)                  # reproducible: same generator history, same keys
+    assert seed_to_key(h.bit_generator) not in (k1, k2)                  # a BitGenerator spawns from the same sequence
     pdf = gs.MixtureModel([gs.VonMisesFisher([0.0, 0.0, 5.0])])
     with pytest.raises(ValueError):
         gs.ShrinkageSphericalSliceSampler(pdf, np.eye(3), [1, 2, 3])
@@ -173,3 +193,22 @@ def test_graft_entry_build_passes():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=root, capture_output=True, text=True,
                        timeout=1500)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_group_kernels_do_not_spill():
+    """The curve group kernels the bench times are built for three (d <= 16) / two wavefronts per SIMD WITHOUT scratch: their
+    register budget rests on an internal LLVM option (geosss_amd/build.py probes it) and on the kernel's own structure, and a
+    spilling build would send gigabytes of scratch traffic per launch to HBM (gsss_curvespec.h).  Checked from the compiler's
+    own resource remarks, device code only (hipcc cross-compiles here)."""
+    from geosss_amd import build
+    ru = build.resource_usage("gsss_fast_curvespec.hip")
+    want = {"ILi4ELi1ELi10ELb0ELb0E": 3, "ILi16ELi1ELi10ELb0ELb0E": 3, "ILi4ELi2ELi10ELb0ELb0E": 2, "ILi4ELi4ELi10ELb0ELb0E": 2,
+            "ILi8ELi4ELi10ELb0ELb0E": 2, "ILi16ELi4ELi10ELb0ELb0E": 2}        # <L, Q, NK, replay, stats> -> waves per SIMD
+    seen = 0
+    for name, r in ru.items():
+        for key, waves in want.items():
+            if "curvespec_kernel" + key in name:
+                seen += 1
+                assert r["scratch"] == 0, (name, r)
+                assert r["occupancy"] >= waves, (name, r)
+    assert seen == len(want), sorted(ru)

@@ -26,6 +26,19 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
 
 
+def test_rccl_ranks_need_one_gpu_each():
+    """Under the RCCL backend a rank per GPU: fewer visible GPUs than --gpus is refused with a one-line reason and a non-zero
+    exit before any process group is formed (nothing hangs in a rendezvous)."""
+    import torch
+    have = torch.cuda.device_count()
+    want = have + 2
+    r = _run(["--gpus", str(want), "--no-cpu-baseline"], {"WORLD_SIZE": str(want), "RANK": "0", "LOCAL_RANK": "0",
+                                                          "GSSS_BENCH_BACKEND": "nccl"}, timeout=120)
+    assert r.returncode == 3, r.stderr[-2000:]
+    assert f"needs {want} visible GPUs" in r.stderr and not r.stdout.strip()
+    assert r.stderr.strip().count("\n") == 0      # one line
+
+
 def test_self_launch_reaches_the_gpu_check():
     import torch
     if torch.cuda.is_available():
@@ -49,6 +62,11 @@ def test_two_ranks_end_to_end_on_one_gpu():
     assert out["n_gpus"] == 2 and out["rccl"]["ranks_seen"] == 2 and out["rccl"]["backend"] == "gloo"
     assert out["chains_in_error"] == 0 and out["value"] > 0
     assert 4.5 < out["tries_per_step"] < 5.6
+    # imbalance between ranks is visible in the line: per-rank kernel time (min / max / all) and wall clock, the gather's time
+    kr = out["rccl"]["kernel_ms_per_rank"]
+    assert len(kr["all"]) == 2 and 0 < kr["min"] <= kr["max"] and out["rccl"]["gather_ms"] > 0
+    assert 0 < out["rccl"]["wall_ms_per_rank"]["min"] <= out["rccl"]["wall_ms_per_rank"]["max"]
+    assert "philox-v2" in out["config"]["stream"] and "meaning" in out["roofline_valu"]
     # one rank, same flags: the same JSON schema and a comparable per-GPU rate
     one = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--chains", "20000", "--inner", "100", "--thin", "50",
                 "--no-cpu-baseline", "--no-ess", "--no-configs"])

@@ -193,3 +193,79 @@ def test_baselines_sample_the_target(gs):
         s.advance(steps)
         m = np.mean(s.state[:, :10] ** 2, axis=0)
         assert np.max(np.abs(m - m_ref)) < 0.02, (cls.__name__, m, m_ref)
+
+
+# ------------------------------------------------------------------ round 3
+
+
+def _per_step_rows(draws, offsets):
+    n = len(offsets) - 1
+    out = np.full((n, int(np.max(np.diff(offsets)))), 0.5)
+    for i in range(n):
+        out[i, : offsets[i + 1] - offsets[i]] = draws[offsets[i]: offsets[i + 1]]
+    return out
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c.startswith("mh_hmc_")])
+def test_hmc_single_transition_teacher_forced(gs, name):
+    """Every recorded transition of the reference's SphericalHMC at once: chain i starts from reference state i with the
+    stepsize the reference used in step i and replays that step's draws; the state after ONE transition (ten leapfrog steps,
+    the accept decision) equals the reference's at the north-star tolerance 1e-10 -- the free-running chains above are held to
+    1e-9 because rounding is amplified from transition to transition, not within one."""
+    z = golden(name + ".npz")
+    states, n = z["states"], len(z["states"]) - 1
+    eps = np.concatenate([[float(z["stepsize0"])], z["stepsize_trace"][:-1]])       # the stepsize step i starts with
+    s = build(gs, z, states[:-1], 1)
+    s.reset(0)                                                                       # (adaptation comes after the move)
+    s.stepsize = eps
+    s.advance(1, replay=_per_step_rows(z["draws"], z["step_draw_offset"]))
+    assert np.all(s.errors == 0)
+    got = s.state[:, : states.shape[1]]
+    moved = np.any(got != states[:-1], axis=1)
+    h = horizon(z) if str(z["target_kind"]) != "cpd" else n       # one transition each: the whole recorded chain, registration too
+    assert np.array_equal(moved[:h], z["accept"].astype(bool)[:h])
+    assert np.max(np.abs(got[:h] - states[1:h + 1])) < 1e-10
+    if "momenta_trace" in z.files:                                 # the momentum half of the reference's rows (mcmc.py:262)
+        assert np.max(np.abs(s.momenta[:h] - z["momenta_trace"][1:h + 1])) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["mh_hmc_vmfmix_readme", "mh_hmc_bingham_d10_vmax30", "mh_hmc_curve_d10_kappa800"])
+def test_hmc_sample_returns_momenta(gs, name):
+    """SphericalHMC.sample(n, burnin, return_momenta=True) -> (positions, momenta), the two halves of the reference's [x, v]
+    rows (mcmc.py:321-332), from the seed alone on numpy's stream; row 0 is the initial state with zero momenta."""
+    z = golden(name + ".npz")
+    n, burn, d = len(z["states"]) - 1, int(z["burnin"]), len(z["x0"])
+    s = build(gs, z, z["x0"], int(z["seed"]), rng="numpy")
+    pos, mom = s.sample(n + 1 - burn, burn, return_momenta=True, return_all_samples=True)
+    assert pos.shape == mom.shape == (n + 1, d)
+    assert np.array_equal(pos[0], z["x0"]) and np.all(mom[0] == 0.0)
+    assert np.max(np.abs(pos - z["states"])) < 1e-9 and np.max(np.abs(mom - z["momenta_trace"])) < 1e-7
+    assert np.max(np.abs(np.einsum("ij,ij->i", pos[1:], mom[1:]))) < 1e-9       # tangent momenta
+    # without the burn-in rows, many chains, device tensors
+    t = build(gs, z, np.tile(z["x0"], (5, 1)), 3)
+    p2, m2 = t.sample(12, burnin=6, return_momenta=True, as_tensor=True)
+    assert p2.shape == m2.shape == (5, 12, d) and p2.is_cuda and m2.is_cuda
+    assert np.allclose(m2[:, -1].cpu().numpy(), t.momenta) and np.array_equal(p2[:, -1].cpu().numpy(), t.state[:, :d])
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c.startswith("mh_mix_")])
+def test_mixture_kernel_records_rwmh_stepsizes(gs, name):
+    """MixtureRWMHIndependenceSampler.rwmh_stepsize_vals (mcmc.py:201, 228): the stepsize after every RWMH proposal, from the
+    seed alone on numpy's stream -- the reference's list, entry for entry."""
+    z = golden(name + ".npz")
+    s = build(gs, z, z["x0"], int(z["seed"]), rng="numpy")
+    s.reset(int(z["burnin"]))
+    s.advance(len(z["states"]) - 1)
+    vals = s.rwmh_stepsize_vals
+    assert isinstance(vals, list) and len(vals) == int(z["rwmh_counter"]) == s.rwmh_counter
+    assert np.max(np.abs(np.array(vals) / z["rwmh_stepsize_vals"] - 1)) < 1e-12
+    many = gs.MixtureRWMHIndependenceSampler(product_target(z), np.tile(z["x0"], (3, 1)), 5, mixing_probability=float(z["alpha"]))
+    with pytest.raises(ValueError):
+        many.rwmh_stepsize_vals                                   # an ensemble records them on request only
+    many = gs.MixtureRWMHIndependenceSampler(product_target(z), np.tile(z["x0"], (3, 1)), 5, mixing_probability=float(z["alpha"]),
+                                             record_stepsize=True)
+    many.reset(10)
+    many.advance(7)
+    many.advance(30)
+    per = many.rwmh_stepsize_vals
+    assert [len(v) for v in per] == list(many.rwmh_counter_per_chain) and all(np.all(v > 0) for v in per)
