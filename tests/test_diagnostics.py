@@ -128,3 +128,38 @@ def test_spiral_grid_and_grid_kl():
     want = float(np.sum(p * (np.log(p) - np.log(q))))
     got = D.grid_kl(Pdf(), np.stack([u, u]), 1500)
     assert got.shape == (2,) and abs(got[0] - want) < 1e-9
+
+
+def test_ess_bulk_known_regimes():
+    """diagnostics.ess_bulk (rank-normalised split-chain bulk ESS, the estimator behind the paper's "relative ESS",
+    scripts/bingham.py:43-57) in regimes with a known answer: independent draws -> relative ESS ~ 1; an AR(1) series with
+    coefficient phi -> (1 - phi) / (1 + phi); invariance under monotone transforms of the data (it only sees ranks); chains
+    that disagree about the mean -> a small ESS whatever their own mixing; antithetic draws -> above 1 (capped by log10)."""
+    from geosss_amd import diagnostics as D
+    rng = np.random.default_rng(5)
+    iid = rng.standard_normal((10, 20000))
+    r = D.ess_bulk(iid, relative=True)
+    assert 0.93 < r < 1.07, r
+    assert abs(D.ess_bulk(iid) / iid.size - r) < 1e-12
+    assert abs(D.ess_bulk(np.exp(3 * iid), relative=True) - r) < 1e-12          # ranks only
+    for phi in (0.5, 0.9):
+        e = rng.standard_normal((10, 50000))
+        x = np.empty_like(e)
+        x[:, 0] = e[:, 0] / np.sqrt(1 - phi * phi)
+        for t in range(1, e.shape[1]):
+            x[:, t] = phi * x[:, t - 1] + e[:, t]
+        got, want = D.ess_bulk(x, relative=True), (1 - phi) / (1 + phi)
+        assert abs(got / want - 1) < 0.08, (phi, got, want)
+    shifted = iid + np.arange(10)[:, None]
+    assert D.ess_bulk(shifted, relative=True) < 1e-3
+    anti = np.empty((4, 10000))
+    anti[:, 0::2] = rng.standard_normal((4, 5000))
+    anti[:, 1::2] = -anti[:, 0::2]
+    assert D.ess_bulk(anti, relative=True) > 1.5
+    t = torch.as_tensor(iid)
+    assert abs(D.ess_bulk(t, relative=True) - r) < 1e-12
+    with pytest.raises(ValueError):
+        D.ess_bulk(np.zeros(10))
+    ties = np.round(iid, 1)                                                     # heavy ties: average ranks, like scipy's rankdata
+    from scipy.stats import rankdata
+    assert np.array_equal(D._average_ranks(torch.as_tensor(ties.reshape(-1))).numpy(), rankdata(ties.reshape(-1)))
