@@ -129,7 +129,7 @@ __device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &s
         merge(best1, dot1, idx1, o1, p1, i1);                                                           \
     } while (0)
     GSSS_CS_STAGE(kDppXor1);
-    GSSS_CS_STAGE(kDppXor2);
+    if (L >= 4) GSSS_CS_STAGE(kDppXor2);
     if (L >= 8) GSSS_CS_STAGE(kDppHalfMirror);
     if (L >= 16) GSSS_CS_STAGE(kDppMirror);
 #undef GSSS_CS_STAGE

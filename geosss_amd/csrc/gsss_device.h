@@ -429,7 +429,7 @@ struct CoopVec {
     static constexpr bool kExactDim = false;  // any d <= DPAD
     __device__ static __forceinline__ int comp(int g, int i) { return 4 * (g + L_ * (i >> 2)) + (i & 3); }
     // sum over the L lanes of a group: every lane ends with the same bits
-    static_assert(L_ == 4 || L_ == 8 || L_ == 16 || L_ == 64, "group sizes with a DPP reduction");
+    static_assert(L_ == 2 || L_ == 4 || L_ == 8 || L_ == 16 || L_ == 64, "group sizes with a DPP reduction");
     __device__ static __forceinline__ double reduce(double v) { return group_sum<L_>(v); }
 };
 

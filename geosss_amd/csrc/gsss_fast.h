@@ -1041,7 +1041,16 @@ __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(Ta
     const int d = tb.d;
     const int g = threadIdx.x % V::L;
     const int64_t n = a.n_chains;
-    const int64_t c_raw = (int64_t)blockIdx.x * (kBlock / V::L) + threadIdx.x / V::L;
+    // this workgroup's work: the whole launch of the chunk it was launched for, or -- sliced (SliceSched, gsss_device.h) -- the
+    // (chunk, step slice) of the ticket it draws
+    __shared__ uint32_t sched_word[4];
+    const bool sliced = a.sched != nullptr;
+    uint32_t chunk = blockIdx.x;
+    int32_t s_begin = 0, len = (int32_t)a.n_steps;  // (fast mode: < 2^31 steps per launch)
+    bool timed_out = false;
+    if (sliced && !SliceSched::take(a, kBlock / V::L, sched_word, chunk, s_begin, len, timed_out)) return;
+    const uint64_t step0 = a.step_offset + (uint64_t)s_begin;  // global id of the first step run here
+    const int64_t c_raw = (int64_t)chunk * (kBlock / V::L) + threadIdx.x / V::L;
     const bool active = c_raw < n;
     const int64_t c = active ? c_raw : n - 1;
     const bool shrink = a.sampler == GSSS_SHRINK;
@@ -1078,10 +1087,19 @@ __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(Ta
     auto my = tp.mine_init(g);
     double lvl = 0.0;
     int64_t n_try = 0, steps_done = 0;
-    int64_t until_keep = a.thin, row = 0;
+    // (a chain that is alive has made every step so far: retained rows follow from the first step run here)
+    int64_t until_keep = a.thin - s_begin % a.thin, row = s_begin / a.thin;
+    bool stopped = false;  // sliced: the chain stopped with an error flag in an earlier slice of this launch
+    if (sliced) {
+        stopped = SliceSched::dead(a, kBlock / V::L)[c] != 0;
+        if (timed_out && !stopped) {  // cannot happen (SliceSched::take); never compute from a state that is not there
+            err |= GSSS_CHAIN_MAX_TRIES | GSSS_CHAIN_COUNTER_SATURATED;
+            stopped = true;
+        }
+    }
 
-    for (int64_t s = 0; s < a.n_steps && !err; ++s) {
-        dr.begin_step(a.step_offset + (uint64_t)s);
+    for (int32_t s = 0; s < len && !err && !stopped; ++s) {
+        dr.begin_step(step0 + (uint64_t)s);
         double u[V::N], u_thr, u_th0;
         if (REPLAY) {
             const bool ok = cursor + d <= a.replay_stride;
@@ -1114,7 +1132,9 @@ __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(Ta
 #pragma unroll
             for (int i = 0; i < V::N; ++i) u[i] *= rnw;
         }
-        const bool refresh = (s % kCoefRefresh) == 0;
+        // (carried coefficients are formed from x again at the first step run here and wherever the GLOBAL step id is a multiple of
+        // kCoefRefresh -- where a sliced launch cuts, so that slicing does not change a bit)
+        const bool refresh = s == 0 || ((step0 + (uint64_t)s) % kCoefRefresh) == 0;
         if constexpr (TP::kQuadratic) {
             tp.make_coop(cf, x, u, g, scratch);
         } else if constexpr (TP::kDistributed) {  // every lane keeps only the coefficients of its own segment
@@ -1228,8 +1248,10 @@ __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(Ta
             if (a.n_reject) a.n_reject[c] += n_try - steps_done;
             if (a.n_tries) a.n_tries[c] += n_try;
             if (a.err && err) a.err[c] |= err;
+            if (sliced && err) SliceSched::dead(a, kBlock / V::L)[c] = 1;  // (every error flag of this kernel stops the chain)
         }
     }
+    if (sliced) SliceSched::publish(a, sched_word);
 }
 
 template <class V, class TP>
@@ -1262,9 +1284,15 @@ int do_coopfast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStrea
         }
     }
     const int64_t per_block = kBlock / V::L;
-    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
+    // more chunks than the chip holds at once: one workgroup per (chunk, step slice), tickets (SliceSched, gsss_device.h)
+    const SlicePlan plan = plan_slices(kern, lds, rb, n_chunks, !replay, st);
+    RunBlock rbl = rb;
+    rbl.sched = plan.ws;
+    rbl.slice_steps = plan.slice_steps;
+    hipLaunchKernelGGL(kern, dim3((unsigned)plan.grid), dim3(kBlock), lds, st, tb, rbl);
     hipError_t e = hipGetLastError();
+    if (plan.ws) (void)hipFreeAsync(plan.ws, st);
     if (e != hipSuccess) {
         set_error("cooperative fast kernel launch failed: %s", hipGetErrorString(e));
         return GSSS_E_HIP;

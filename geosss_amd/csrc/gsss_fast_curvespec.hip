@@ -17,6 +17,18 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
         if (probe) GSSS_PROBE(lane, "curvespec_kernel<%d, %d, %d>", LL, QQ, tb.k <= 10 ? 10 : 17);          \
         return tb.k <= 10 ? do_curvespec<LL, QQ, 10>(tb, rb, replay, st) : do_curvespec<LL, QQ, 17>(tb, rb, replay, st); \
     } while (0)
+    // d <= 16, <= 10 knots: TWO lanes per chain with eight components each (round 3) -- 32 chains share a wavefront's per-step
+    // serial work instead of 16.  GSSS_CURVE_L2=0 keeps the four-lane groups (A/B timing).
+    if (tb.d <= 16 && tb.k <= 10) {
+        static const bool two = [] {
+            const char *e = getenv("GSSS_CURVE_L2");
+            return !(e && e[0] == '0');
+        }();
+        if (two) {
+            if (probe) GSSS_PROBE(lane, "curvespec_kernel<2, 2, 10>");
+            return do_curvespec<2, 2, 10>(tb, rb, replay, st);
+        }
+    }
     if (tb.d <= 16) GSSS_SPEC(4, 1);
     if (tb.d <= 32) GSSS_SPEC(4, 2);
     if (tb.d <= 48) GSSS_SPEC(4, 3);
