@@ -17,12 +17,15 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
         if (probe) GSSS_PROBE(lane, "curvespec_kernel<%d, %d, %d>", LL, QQ, tb.k <= 10 ? 10 : 17);          \
         return tb.k <= 10 ? do_curvespec<LL, QQ, 10>(tb, rb, replay, st) : do_curvespec<LL, QQ, 17>(tb, rb, replay, st); \
     } while (0)
-    // d <= 16, <= 10 knots: TWO lanes per chain with eight components each (round 3) -- 32 chains share a wavefront's per-step
-    // serial work instead of 16.  GSSS_CURVE_L2=0 keeps the four-lane groups (A/B timing).
+    // d <= 16, <= 10 knots: TWO lanes per chain with eight components each were measured in round 3 (32 chains share a
+    // wavefront's per-step serial work instead of 16) and LOST: 25.6 against 20.7 ms per 10^8 chain-steps at d = 10 -- batches of
+    // two speculative tries need 3.9 instead of 2.3 rounds of the single-precision curve evaluation per step, and eight
+    // components per lane only fit three wavefronts per SIMD with u parked in LDS and 36 B of scratch.  GSSS_CURVE_L2=1 runs
+    // them (parity-tested: the kernel is generic in L), the default stays with four-lane groups.
     if (tb.d <= 16 && tb.k <= 10) {
         static const bool two = [] {
             const char *e = getenv("GSSS_CURVE_L2");
-            return !(e && e[0] == '0');
+            return e && e[0] == '1';
         }();
         if (two) {
             if (probe) GSSS_PROBE(lane, "curvespec_kernel<2, 2, 10>");
