@@ -238,10 +238,19 @@ def measured_traffic(workload, n, S, thin, mode):
     return rec["bytes_per_launch"], rec["source"]
 
 
-def hbm_bytes_per_step(d, thin, S):
+def hbm_bytes_per_step(d, thin, S, slice_steps=0):
     """Algorithmic HBM bytes per chain-step: retained sample 8d/thin + state load and
-    store 16d/S + the two int64 counters read-modify-written per launch 32/S."""
-    return 8.0 * d / thin + (16.0 * d + 32.0) / S
+    store 16d/S + the two int64 counters read-modify-written per launch 32/S; a SLICED launch hands
+    state and counters over through HBM once per slice: S is then the slice length."""
+    return 8.0 * d / thin + (16.0 * d + 32.0) / (min(S, slice_steps) if slice_steps > 0 else S)
+
+
+def last_slice_steps(gs):
+    """Slice length of this thread's last sampler launch (0: unsliced), gsss_last_launch."""
+    import ctypes as C
+    grid, steps = C.c_int64(0), C.c_int32(0)
+    gs._lib.load().gsss_last_launch(C.byref(grid), C.byref(steps))
+    return int(steps.value)
 
 
 def free_port():
@@ -288,7 +297,8 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True):
     tps = (int(s._n_tries.sum().item()) - tries0) / (n * S * reps)
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
-    bytes_launch = hbm_bytes_per_step(d, thin, S) * n * S
+    slice_steps = last_slice_steps(gs)
+    bytes_launch = hbm_bytes_per_step(d, thin, S, slice_steps) * n * S
     traffic, src = measured_traffic(name, n, S, thin, s.mode)
     value = n * S * reps / dt
     # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
@@ -296,7 +306,7 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True):
     ess_steps, ess_thin = (8192, 32) if name.startswith("curve") else ((2000, 8) if name.startswith("bingham") else (2000, 4))
     ess_out = ess_per_sec(gs, s, pdf, value, n_steps=ess_steps, thin=ess_thin) if ess else None
     return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}",
-            "stream": stream_description(d),
+            "stream": stream_description(d), "slice_steps": slice_steps,
             "value": value, "unit": "chain-steps/s", "launches": reps, "mode": s.mode, "ess": ess_out,
             "kernel": lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(),
             "kernel_ms": kern_ms, "tries_per_step": tps, "chains_in_error": int((s._err != 0).sum().item()),
@@ -434,7 +444,8 @@ def main(argv=None):
     value = total_steps / elapsed
 
     if rank == 0:
-        bytes_per_launch = hbm_bytes_per_step(d, thin, S) * n * S
+        slice_steps = last_slice_steps(gs)
+        bytes_per_launch = hbm_bytes_per_step(d, thin, S, slice_steps) * n * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
@@ -446,7 +457,7 @@ def main(argv=None):
             "config": {"workload": f"{args.workload}: shrinkage slice sampler, {n} chains/GPU x {S} transitions per "
                                    "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
                        "stream": stream_description(d),
-                       "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S,
+                       "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
                        "mode": sampler.mode,
                        "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
                        "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"

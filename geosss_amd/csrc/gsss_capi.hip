@@ -19,6 +19,9 @@ namespace gsss {
 // ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
+static thread_local LaunchInfo g_last_launch = {0, 0};
+LaunchInfo &last_launch() { return g_last_launch; }
+
 void set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -507,6 +510,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("chain / step ids exceed the 48-bit counter space");
         return GSSS_E_INVALID;
     }
+    last_launch() = LaunchInfo{0, 0};
     if (a->n_chains == 0) return GSSS_OK;
     if (!a->state_dev) {
         set_error("state_dev is null");
@@ -630,6 +634,13 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     }
     set_error("corrupt target");
     return GSSS_E_INVALID;
+}
+
+int gsss_last_launch(int64_t *grid_out, int32_t *slice_steps_out)
+{
+    if (grid_out) *grid_out = last_launch().grid;
+    if (slice_steps_out) *slice_steps_out = last_launch().slice_steps;
+    return GSSS_OK;
 }
 
 int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags, int32_t flags)

@@ -363,7 +363,10 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
                 coef[NK + r] = au;
                 if (refresh) coef[r] = axr;
                 // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
-                if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+#ifndef GSSS_DOT_GROUP
+#define GSSS_DOT_GROUP 2
+#endif
+                if (r % GSSS_DOT_GROUP == GSSS_DOT_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -452,7 +455,10 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
             float s32, c32f;
             sincos_rev32(my_theta, s32, c32f);
             const bool mine = !done && g < valid && t_base + g < max_tries;
-            const float my_b = c32s.best32(q, c32f, s32);
+#ifndef GSSS_SEG_PRELOAD
+#define GSSS_SEG_PRELOAD 1
+#endif
+            const float my_b = c32s.template best32<(GSSS_SEG_PRELOAD != 0) && (Q >= 2)>(q, c32f, s32);
             const float gap = my_b - q[2 * NK];
             int verdict = mine ? (gap < -q[2 * NK + 1] ? -1 : (gap > q[2 * NK + 1] ? 1 : 0)) : -1;
             // first try of the group that is not certainly rejected; an undecided one is decided in double precision by its lane

@@ -150,11 +150,18 @@ struct SlicePlan {
     int64_t grid = 0;
     int32_t slice_steps = 0;
 };
+// what the calling thread's last gsss_run launched (gsss_last_launch): grid 0 = a kernel that does not plan slices
+struct LaunchInfo {
+    int64_t grid;
+    int32_t slice_steps;
+};
+LaunchInfo &last_launch();  // gsss_capi.hip, thread local
 template <class Kern>
 inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, int64_t n_chunks, bool allowed, hipStream_t st)
 {
     SlicePlan p;
     p.grid = n_chunks;
+    last_launch() = LaunchInfo{n_chunks, 0};
     if (!allowed) return p;
     const char *env = getenv("GSSS_SLICE_STEPS");  // (read per launch: tests switch it)
     const int env_val = env ? atoi(env) : 128;  // (measured at 10^5 chains x 1000 steps, d = 10 / 50 / 200: 64 -> 24.1 / 40.0 / 107.3 ms, 128 -> 23.8 / 39.7 / 106.1)
@@ -184,6 +191,7 @@ inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, in
     p.ws = static_cast<uint32_t *>(ws);
     p.grid = n_chunks * (1 + (rest > 0 ? (rest + env_steps - 1) / env_steps : 0));  // = SliceSched::take's n_items
     p.slice_steps = env_steps;
+    last_launch() = LaunchInfo{p.grid, p.slice_steps};
     return p;
 }
 

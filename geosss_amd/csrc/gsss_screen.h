@@ -289,14 +289,22 @@ struct Curve32 {
     // margin, eval_error); continuous across the branch boundaries (t* = 0: |P y| / sin = a.y; t* = theta_g: = b.y), so the
     // Lipschitz bound of the margin holds whichever branch the single-precision evaluation takes.  16 instead of 34 vector
     // instructions a segment (no three-way select, v_sqrt instead of v_rsq and two products).
+    template <bool PRELOAD = false>
     __device__ __forceinline__ float best32(const float (&q)[kFloats], float c, float s) const
     {
         float best = -INFINITY;
         float ay = fmaf(c, q[0], s * q[NK]);
+        // PRELOAD (kernels with registers to spare: two wavefronts per SIMD): all segments' constants are read in one go -- one
+        // LDS round trip per evaluation instead of one per segment in front of its first use
+        float4 pre[PRELOAD ? NK - 1 : 1];
+        if (PRELOAD) {
+#pragma unroll
+            for (int g = 0; g + 1 < NK; ++g) pre[g] = seg32[g];
+        }
 #pragma unroll
         for (int g = 0; g + 1 < NK; ++g) {
             const float by = fmaf(c, q[g + 1], s * q[NK + g + 1]);
-            const float4 sg = seg32[g];
+            const float4 sg = PRELOAD ? pre[PRELOAD ? g : 0] : seg32[g];
             const float ct = sg.x, st = sg.y, rden = sg.z;
             const float A = ay * st;
             const float B = fmaf(-ay, ct, by);

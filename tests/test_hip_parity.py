@@ -797,10 +797,12 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
         assert _packed_kernel(s).startswith(("curvespec_kernel", "coopfast_kernel"))
         kept = [s.advance(m, thin=7) for m in steps]
         out[label] = (s.state_device.clone(), torch.cat(kept), s._n_tries.clone(), s._n_reject.clone(), s._err.clone())
-    for label in ("s64", "s128"):
-        for i in range(5):
-            assert torch.equal(out["whole"][i], out[label][i]), (label, i)
     err = out["whole"][4]
+    ok = err == 0                                # (a stopped chain writes no further rows: those slots of the buffer are unspecified)
+    for label in ("s64", "s128"):
+        for i in (0, 2, 3, 4):
+            assert torch.equal(out["whole"][i], out[label][i]), (label, i)
+        assert torch.equal(out["whole"][1][:, :, ok], out[label][1][:, :, ok]), label
     if sampler == "shrink":
         assert 0 < int((err != 0).sum()) < n_chains               # stopped chains and healthy ones, both kinds in every slice
     else:
