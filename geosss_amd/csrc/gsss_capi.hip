@@ -424,7 +424,8 @@ int gsss_target_create(const gsss_target_desc *desc, int device, gsss_target **o
     t->tb.blob = t->blob_dev;
     t->tb.kind = desc->kind;
     t->tb.d = d;
-    t->tb.k = desc->kind == GSSS_BINGHAM ? (bingham_diagonal ? 1 : 0) : k;  // Bingham: k flags a diagonal A
+    // Bingham: k holds flags -- bit 0 a diagonal A, bit 1 a linear term (BinghamFisher)
+    t->tb.k = desc->kind == GSSS_BINGHAM ? ((bingham_diagonal ? 1 : 0) | (desc->mu ? 2 : 0)) : k;
     if (desc->kind == GSSS_CPD) t->tb.k = k | (desc->n_target << 16);       // registration: both cloud sizes
     t->cpd_variant = cpd_variant;
     t->tb.dpad = 0;

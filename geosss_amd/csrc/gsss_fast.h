@@ -173,7 +173,7 @@ struct FastBingham {
         for (int i = threadIdx.x; i < D * D + D; i += kBlock) lds[i] = tb.blob[i];
         A = lds;
         b = lds + D * D;
-        diagonal = tb.k == 1;
+        diagonal = (tb.k & 1) != 0;
     }
     __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D], double /*lvl*/,
                                            bool /*fresh*/) const
@@ -958,7 +958,7 @@ struct CoopBingham {
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         d = tb.d;
-        diagonal = tb.k == 1;
+        diagonal = (tb.k & 1) != 0;
         lds_fill(lds, tb.d + 1, V::DPAD, tb.blob, tb.d);
         A = lds;
         b = lds + (size_t)tb.d * V::DPAD;

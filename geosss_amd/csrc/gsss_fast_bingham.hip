@@ -7,14 +7,19 @@ namespace gsss {
 
 int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *probe, hipStream_t st)
 {
+    // tb.k: bit 0 a diagonal A, bit 1 a linear term.  The paper's eigenbasis targets (diagonal, no linear term) run the compact
+    // screen target (three wavefronts per SIMD at d = 9, 10: ScreenBinghamDiag, gsss_screen.h)
 #define GSSS_CASE(D)                                               \
     if (tb.d == D) {                                               \
         const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr; \
+        const bool compact = tb.k == 1;                            \
         if (probe) {                                               \
+            if (rb.screen && compact) GSSS_PROBE(true, "screened_kernel<%d, ScreenBinghamDiag<%d>>", D, D); \
             if (rb.screen) GSSS_PROBE(true, "screened_kernel<%d, ScreenBingham<%d>>", D, D); \
             GSSS_PROBE(true, "fast_kernel<%d, FastBingham<%d>>", D, D); \
         }                                                          \
         if (!screen) return do_fast<D, FastBingham<D>>(tb, rb, replay, st); \
+        if (compact) return replay ? do_screened_run<D, ScreenBinghamDiag<D>, true>(tb, rb, st) : do_screened_run<D, ScreenBinghamDiag<D>, false>(tb, rb, st); \
         return replay ? do_screened_run<D, ScreenBingham<D>, true>(tb, rb, st) : do_screened_run<D, ScreenBingham<D>, false>(tb, rb, st); \
     }
     GSSS_FAST_BINGHAM_DIMS(GSSS_CASE)
@@ -26,7 +31,7 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
         // and Box-Muller rounds, reductions, the try loop -- is repeated in every lane of a group, and sixteen groups share a
         // wavefront); d <= 64 eight lanes with eight slots for a diagonal A (3.0 against 2.6), sixteen with four for a dense
         // one (its d x d products want the lanes: 1.36 against 1.26).
-        const bool diag = tb.k == 1;
+        const bool diag = (tb.k & 1) != 0;
         const int ll = tb.d <= 32 ? 4 : (tb.d <= 64 && diag ? 8 : 16), ss = tb.d <= 16 ? 4 : (tb.d <= 32 || tb.d > 64 || diag ? 8 : 4);
         if (probe) GSSS_PROBE(false, "coopfast_kernel<CoopVec<%d, %d>, CoopBingham>", ll, ss);
         if (tb.d <= 16) return do_coopfast<CoopVec<4, 4>, CoopBingham<CoopVec<4, 4>>>(tb, rb, replay, st);

@@ -89,6 +89,8 @@ struct ScreenVmf : FastVmf<D, KC> {
     // when 24 lanes want to is worth 9 % (K = 10, kappa = 500: 56.6 -> 51.7 ms per 10^9 chain-steps; 12: 52.5, 32: 59.2, 44: 71.7);
     // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
     static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
+    static constexpr bool kCompact = false;
+    __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&x)[D], const double (&u)[D], float (&q)[kCoef32Floats]) const
     {
         constexpr double L = 1.4426950408889634074;
@@ -215,6 +217,8 @@ struct ScreenBingham : FastBingham<D> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 6;
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
+    static constexpr bool kCompact = false;
+    __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
     {
@@ -263,6 +267,91 @@ struct ScreenBingham : FastBingham<D> {
     {
         Coef cf;
         const double thr = threshold(cf, x, u, u_thr);
+        return level_exact(cf, c, s) > thr;
+    }
+};
+
+// Bingham with a DIAGONAL A and no linear term -- the eigenbasis targets of the paper (random_bingham(eigensystem=True),
+// scripts/bingham.py:131; BASELINE cfg3) -- with a COMPACT parked state (round 3).  The lane kernel keeps a second chain per lane
+// parked in LDS; at d = 10 that state was 28 words (x, u, bracket, threshold uniform, six single-precision floats, counters):
+// 57 KB per workgroup, two workgroups per CU, two wavefronts per SIMD -- the vector pipes issued 77 % of the time.  Here:
+//   * only the d diagonal entries are staged (80 B instead of 880 B of parameters);
+//   * three coefficients (no b.x, b.u), so the pack is q0, q1, q2 + margin, and the margin is not parked but formed again from
+//     q0 .. q2 when a chain is taken up (retail(): the same expression as at set-up, a dozen instructions);
+//   * the threshold uniform is not parked: an undecided try (rare) draws it again from the counter-based stream;
+//   * the row of the next retained sample is not parked: it follows from the step count (one exact integer division at the
+//     end of a step, only when samples or statistics are kept).
+// 25 words = 51 200 B per workgroup: three workgroups per CU (3 x 53 888 B <= 160 KB), three wavefronts per SIMD.
+// Arithmetic: FastBingham's diagonal branch operation for operation (b = 0 adds exact zeros there), so the chains are those of
+// fast_kernel<D, FastBingham<D>> bit for bit (test_screened_equals_double).
+template <int D>
+struct ScreenBinghamDiag {
+    static constexpr bool kLinear = false;
+    static constexpr int kCoef32Floats = 4;  // q0 = -log U, q1 = qxu, q2 = (quu - qxx) - log U | margin
+    static constexpr int kParkSkip = 0, kMinWaves = D >= 9 ? 3 : 1, kTradeMin = 1;
+    static constexpr bool kCompact = true;
+    const double *a;  // LDS [D]: the diagonal of A
+    struct Coef {
+        double qxx, qxu, quu;
+    };
+    __host__ __device__ static size_t lds_doubles() { return (size_t)D; }
+    __device__ void stage(double *lds, const TargetBlock &tb)
+    {
+        for (int i = threadIdx.x; i < D; i += kBlock) lds[i] = tb.blob[(size_t)i * D + i];
+        a = lds;
+    }
+    __device__ __forceinline__ double make(Coef &cf, const double (&x)[D], const double (&u)[D]) const
+    {
+        double qxx = 0.0, qxu = 0.0, quu = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {  // FastBingham::make, diagonal branch
+            const double ajj = a[j];
+            const double xa = x[j] * ajj, ua = u[j] * ajj;
+            qxx = fma(xa, x[j], qxx);
+            qxu = fma(xa, u[j], fma(ua, x[j], qxu));
+            quu = fma(ua, u[j], quu);
+        }
+        cf.qxx = qxx;
+        cf.qxu = qxu;
+        cf.quu = quu;
+        return qxx + 0.0;  // (+ b.x = 0, as there)
+    }
+    __device__ __forceinline__ double level_exact(const Coef &cf, double c, double s) const
+    {
+        return fma(c * c, cf.qxx, fma(c * s, cf.qxu, (s * s) * cf.quu)) + fma(c, 0.0, s * 0.0);  // FastBingham::level with bx = bu = 0
+    }
+    // margin from the parked coefficients alone: |log2 U| <= 1.4428 |q0| bounds the logarithm's error terms of ScreenBingham::make32
+    __device__ __forceinline__ void retail(float (&q)[kCoef32Floats]) const
+    {
+        const float sum = fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]);
+        const float l2 = 1.4428f * fabsf(q[0]);
+        const float e_lu = (kLog2Err32 + 2.0f * kUnit32 * l2) * 0.6932f + kUnit32 * (2.0f * fabsf(q[0]) + fabsf(q[2]));
+        float margin = 1.25f * (sum * (2.0f * kSinCosErr32 + 6.0f * kUnit32) + e_lu) + 1.0e-30f;
+        if (!(margin < 1.0e30f)) margin = INFINITY;  // (U = 0 or NaN: q0 is not finite -- double precision decides every try)
+        q[3] = margin;
+    }
+    __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
+    __device__ __forceinline__ bool setup32(const double (&x)[D], const double (&u)[D], double u_thr, float (&q)[kCoef32Floats]) const
+    {
+        Coef cf;
+        const double lvl0 = make(cf, x, u);
+        const float lu = log2_32(u_thr) * 0.69314718f;  // log U in single precision: its error is in the margin (ScreenBingham::make32)
+        q[0] = 0.0f - lu;                                // (float)(qxx - lvl0) = 0 exactly
+        q[1] = (float)cf.qxu;
+        q[2] = (float)(cf.quu - lvl0) - lu;
+        if (!(u_thr > 1e-290)) q[0] = INFINITY;
+        retail(q);
+        return lvl0 > -INFINITY && lvl0 < INFINITY;
+    }
+    __device__ __forceinline__ int screen(const float (&q)[kCoef32Floats], float c, float s) const
+    {
+        const float g = fmaf(c, fmaf(c, q[0], s * q[1]), s * (s * q[2]));
+        return g < -q[3] ? -1 : (g > q[3] ? 1 : 0);
+    }
+    __device__ __forceinline__ bool decide(const double (&x)[D], const double (&u)[D], double u_thr, double c, double s) const
+    {
+        Coef cf;
+        const double thr = make(cf, x, u) + fm::log_fast(u_thr);  // mcmc.py:389, as fast_kernel forms it
         return level_exact(cf, c, s) > thr;
     }
 };
@@ -403,6 +492,8 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
+    static constexpr bool kCompact = false;
+    __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     Curve32<NK> c32;
     __host__ __device__ static size_t lds_doubles() { return Base::lds_doubles() + 2 * (size_t)(NK - 1); }
@@ -503,8 +594,13 @@ struct ScreenChain {
     float q[kQ];
     uint32_t n_try;
     int32_t steps_done, row, t, status, err, cursor;
-    static constexpr int kWordsNoReplay = 2 * D + 3 + (kQ - kSkip) / 2 + 2;
-    static constexpr int kWords = kWordsNoReplay + 1;
+    // Compact targets (TP::kCompact: ScreenBinghamDiag): the last float of q (the margin) is formed again at take-up
+    // (TP::retail), the threshold uniform is drawn again for an undecided try (not from a replayed stream: there it is parked)
+    // and the retained row follows from the step count -- x, u, lo, hi | q0 q1 | q2 steps_done | n_try flags.
+    static constexpr bool kCompact = TP::kCompact;
+    static_assert(!kCompact || (TP::kCoef32Floats == 4 && kSkip == 0), "compact layout: three parked floats");
+    static constexpr int kWordsNoReplay = kCompact ? 2 * D + 2 + 3 : 2 * D + 3 + (kQ - kSkip) / 2 + 2;
+    static constexpr int kWords = kWordsNoReplay + (kCompact ? 2 : 1);  // replay: + the cursor (compact: + the threshold uniform)
 };
 
 template <int D, class TP>
@@ -520,6 +616,32 @@ __host__ __device__ constexpr size_t screen_lds_doubles()
                                                       : 0);
 }
 
+__device__ __forceinline__ void lds_trade(float &a, int32_t &b, unsigned long long *slot)
+{
+    const unsigned long long mine = (unsigned long long)__float_as_uint(a) | ((unsigned long long)(uint32_t)b << 32);
+    const unsigned long long o = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    a = __uint_as_float((uint32_t)o);
+    b = (int32_t)(uint32_t)(o >> 32);
+}
+
+// n / d and whether d divides n, exactly, for 0 <= n < 2^31 and a wavefront-uniform 0 < d < 2^31 (rcp = 1.0 / d): the
+// double-precision quotient is off by at most one either way
+__device__ __forceinline__ bool divides(int32_t n, int32_t d, double rcp, int32_t &quot)
+{
+    int32_t q = (int32_t)((double)n * rcp);
+    int32_t r = n - q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    }
+    if (r >= d) {
+        ++q;
+        r -= d;
+    }
+    quot = q;
+    return r == 0;
+}
+
 __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long *slot)
 {
     const unsigned long long mine = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
@@ -530,7 +652,7 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
 
 // (measured: asking for two wavefronts per SIMD at d = 10 makes the curve kernel spill 73 registers: 45 -> 64 ms)
 template <int D, class TP, bool REPLAY, bool STATS = false>
-__global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
     using Chain = ScreenChain<D, TP>;
@@ -546,6 +668,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
     const int32_t n_steps = (int32_t)a.n_steps;
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int32_t thin = (int32_t)a.thin;
+    const double rcp_thin = 1.0 / (double)thin;  // (compact chains: the retained row follows from the step count)
     const int32_t max_tries = a.max_tries < (1 << 25) ? a.max_tries : (1 << 25) - 1;  // t shares a word with the flags
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
     constexpr bool kPark = screen_parks<D, TP>();
@@ -713,14 +836,34 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         fm::sincos_tab(theta, tab, sn, cs);
         bool accepted = true;
         if (is_decide(cur.status)) {  // rare: the double-precision test itself (mcmc.py:389, 397)
-            accepted = tp.decide(cur.x, cur.u, cur.thr, cs, sn);
+            double u_thr = cur.thr;
+            if constexpr (Chain::kCompact && !REPLAY) {  // not parked: the step's threshold uniform, drawn again
+                double u_th0;
+                if constexpr (D == 3) {
+                    uint32_t w_phi;
+                    philox().step_s2(u_thr, u_th0, w_phi);
+                } else {
+                    philox().block(0u, u_thr, u_th0);
+                }
+            }
+            accepted = tp.decide(cur.x, cur.u, u_thr, cs, sn);
         }
         if (accepted) {
 #pragma unroll
             for (int j = 0; j < D; ++j) cur.x[j] = fma(sn, cur.u[j], cs * cur.x[j]);  // mcmc.py:396
             count_tries();
             ++cur.steps_done;
-            if ((a.samples != nullptr || STATS) && cur.steps_done == (cur.row + 1) * thin) {
+            bool keep = false;
+            if (a.samples != nullptr || STATS) {
+                if constexpr (Chain::kCompact) {
+                    int32_t rows;
+                    keep = divides(cur.steps_done, thin, rcp_thin, rows);
+                    cur.row = rows - 1;
+                } else {
+                    keep = cur.steps_done == (cur.row + 1) * thin;
+                }
+            }
+            if (keep) {
                 if (a.samples != nullptr) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
@@ -750,14 +893,22 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         for (int j = 0; j < D; ++j) word(cur.u[j]);
         word(cur.lo);
         word(cur.hi);
-        word(cur.thr);
+        if constexpr (Chain::kCompact) {
+            if (REPLAY) word(cur.thr);
+            lds_trade(cur.q[0], cur.q[1], p);
+            p += kBlock;
+            lds_trade(cur.q[2], cur.steps_done, p);
+            p += kBlock;
+        } else {
+            word(cur.thr);
 #pragma unroll
-        for (int i = Chain::kSkip; i < Chain::kQ; i += 2) {
-            lds_trade(cur.q[i], cur.q[i + 1], p);
+            for (int i = Chain::kSkip; i < Chain::kQ; i += 2) {
+                lds_trade(cur.q[i], cur.q[i + 1], p);
+                p += kBlock;
+            }
+            lds_trade(cur.steps_done, cur.row, p);
             p += kBlock;
         }
-        lds_trade(cur.steps_done, cur.row, p);
-        p += kBlock;
         if (REPLAY) {
             int32_t zero = 0;
             lds_trade(cur.cursor, zero, p);
@@ -775,6 +926,7 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         // the chain taken up tries next -- or may, if its undecided try is decided a rejection: its unparked coefficients
         // are formed again (a chain that waits for set-up or for its move gets new ones there / needs none)
         if (Chain::kSkip > 0 && (cur.status == kReady || is_decide(cur.status))) tp.refill(cur.x, cur.u, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
+        if constexpr (Chain::kCompact) tp.retail(reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));  // the margin
     };
 
     auto flush = [&]() {
@@ -806,10 +958,16 @@ __global__ void __launch_bounds__(kBlock, TP::kMinWaves) screened_kernel(TargetB
         for (int j = 0; j < D; ++j) put(cur.u[j]);
         put(cur.lo);
         put(cur.hi);
-        put(cur.thr);
+        if constexpr (Chain::kCompact) {
+            if (REPLAY) put(cur.thr);
+            put2(__float_as_uint(cur.q[0]), __float_as_uint(cur.q[1]));
+            put2(__float_as_uint(cur.q[2]), (uint32_t)cur.steps_done);
+        } else {
+            put(cur.thr);
 #pragma unroll
-        for (int i = Chain::kSkip; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
-        put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
+            for (int i = Chain::kSkip; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
+            put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
+        }
         if (REPLAY) put2((uint32_t)cur.cursor, 0u);
         put2(cur.n_try, (uint32_t)pack_flags());
         parked_status = cur.status;
