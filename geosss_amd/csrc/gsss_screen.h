@@ -1031,6 +1031,11 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     }
     const int per_block = screen_parks<D, TP>() ? 2 * kBlock : kBlock;
     const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
+    if (getenv("GSSS_DEBUG_OCCUPANCY")) {  // (tuning aid: what the runtime says about residency)
+        int per_cu = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds);
+        fprintf(stderr, "gsss: screened kernel: %zu B of LDS per workgroup, %d workgroups per CU, grid %lld\n", lds, per_cu, (long long)grid);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
