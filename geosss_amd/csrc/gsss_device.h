@@ -351,14 +351,17 @@ __device__ __forceinline__ void tangent3(double n0, double n1, double n2, double
 }
 
 // LDS doubles a kernel sets aside for fm::Tables (16-byte aligned inside the dynamic LDS block)
-constexpr int kTabLds = fm::kTableDoubles + 2;
+// (only the 64 points of the circle: the logarithm table of gsss_math.h served the double-precision Box-Muller pairs of round 1
+// and has no user in the kernels since the pairs are formed in single precision -- 1.5 KB per workgroup that the compact
+// Bingham kernel needs for its third workgroup per CU)
+constexpr int kTabLds = 2 * 64 + 2;
 __device__ __forceinline__ fm::Tables stage_tables(double *lds_after_params)
 {
     // one double further if that is what 16-byte alignment takes.  (Pointer + integer: rounding the pointer's integer value
     // up and casting back makes it a generic pointer, and every table read of the kernel a flat_load instead of a ds_read.)
     double *buf = lds_after_params + ((reinterpret_cast<uintptr_t>(lds_after_params) >> 3) & 1u);
-    for (int i = threadIdx.x; i < 64 + fm::kLogTableN; i += kBlock) fm::table_entry(buf, i);
-    return fm::Tables{buf, buf + 128};
+    for (int i = threadIdx.x; i < 64; i += kBlock) fm::table_entry(buf, i);
+    return fm::Tables{buf, nullptr};
 }
 
 constexpr uint64_t kInitStep = 0xFFFFFFFFFFFFull;  // reserved step id: initial states (gsss_sample_sphere)
