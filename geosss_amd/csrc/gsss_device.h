@@ -58,6 +58,8 @@ struct RunBlock {
     // the chip drains for one slice, not for a whole chunk.  Zeroed workspace: [0] ticket | [2 ..) progress[n_chunks] | dead[n_chains].
     uint32_t *sched;
     int32_t slice_steps;       // steps per slice; boundaries sit at multiples of it in GLOBAL step ids
+    int32_t sched_first;       // chunks below this one are not sliced: their workgroups (blockIdx < sched_first) run the whole launch
+                               // (the lane kernels slice only the last, partial round of their workgroups)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -89,14 +91,14 @@ struct SliceSched {
         if (threadIdx.x == 0) *word = __hip_atomic_fetch_add(a.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)*word);
-        const uint32_t n_chunks = chunks(a, per_block);
+        const uint32_t n_chunks = chunks(a, per_block) - (uint32_t)a.sched_first;  // the sliced ones
         const int32_t ss = a.slice_steps, n_steps = (int32_t)a.n_steps;
         const int32_t first_len = ss - (int32_t)(a.step_offset % (uint64_t)ss);
         const int32_t rest = n_steps - first_len;
         const uint32_t n_items = n_chunks * (uint32_t)(1 + (rest > 0 ? (rest + ss - 1) / ss : 0));
         if (t >= n_items) return false;
         const uint32_t slice = t / n_chunks;
-        chunk = t - slice * n_chunks;
+        chunk = (uint32_t)a.sched_first + (t - slice * n_chunks);
         if (threadIdx.x == 0) {
             word[1] = chunk;
             word[2] = slice;
@@ -191,6 +193,55 @@ inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, in
     p.ws = static_cast<uint32_t *>(ws);
     p.grid = n_chunks * (1 + (rest > 0 ? (rest + env_steps - 1) / env_steps : 0));  // = SliceSched::take's n_items
     p.slice_steps = env_steps;
+    last_launch() = LaunchInfo{p.grid, p.slice_steps};
+    return p;
+}
+
+// The lane kernels (two chains per lane, a workgroup's unit of time is a lane's pair of chains) slice only their LAST, PARTIAL
+// round of workgroups, and only when it is small: n_chunks = k resident + rem with rem <= 3/4 resident -- the first k resident
+// workgroups run the whole launch as ever (blockIdx < first), the rem chunks behind them are cut into slices that fill the
+// chip when the full rounds end.  (A slice of a lane kernel ends when its slowest lane does: ~10 % of lane tail at 128 steps,
+// paid on the partial round only.  At 10^6 chains: K = 10 mixture and compact Bingham 2.54 rounds -> sliced; headline 1.91 -> not.)
+template <class Kern>
+inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock &rb, int64_t n_chunks, bool allowed, hipStream_t st,
+                                    int32_t &first_out)
+{
+    SlicePlan p;
+    p.grid = n_chunks;
+    first_out = 0;
+    last_launch() = LaunchInfo{n_chunks, 0};
+    if (!allowed) return p;
+    const char *env = getenv("GSSS_SLICE_STEPS");
+    const int env_val = env ? atoi(env) : 128;
+    const int env_steps = env_val > 0 ? ((env_val + 63) / 64) * 64 : 0;
+    if (env_steps <= 0 || rb.n_steps < 4 * (int64_t)env_steps) return p;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
+        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        return p;
+    }
+    const int64_t resident = (int64_t)per_cu * cus;
+    const int64_t rem = n_chunks % resident, first = n_chunks - rem;
+    if (n_chunks <= resident || rem == 0 || 4 * rem > 3 * resident || rb.n_chains >= 0x7FFFFFFFll) return p;
+    const int64_t first_len = env_steps - (int64_t)(rb.step_offset % (uint64_t)env_steps), rest = rb.n_steps - first_len;
+    const int64_t n_slices = 1 + (rest > 0 ? (rest + env_steps - 1) / env_steps : 0);
+    if (rem * n_slices >= 0x7FFFFFFFll) return p;
+    const size_t bytes = slice_sched_bytes(n_chunks, rb.n_chains);
+    void *ws = nullptr;
+    if (hipMallocAsync(&ws, bytes, st) != hipSuccess || ws == nullptr) {
+        (void)hipGetLastError();
+        return p;
+    }
+    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFreeAsync(ws, st);
+        return p;
+    }
+    p.ws = static_cast<uint32_t *>(ws);
+    p.grid = first + rem * n_slices;
+    p.slice_steps = env_steps;
+    first_out = (int32_t)first;
     last_launch() = LaunchInfo{p.grid, p.slice_steps};
     return p;
 }

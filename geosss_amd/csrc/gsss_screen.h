@@ -665,7 +665,20 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
     __syncthreads();
 
     const int32_t n = (int32_t)a.n_chains;
-    const int32_t n_steps = (int32_t)a.n_steps;
+    // This workgroup's work: its chunk of chains for the whole launch -- or, in the sliced partial round of a launch
+    // (plan_partial_round, gsss_device.h), the (chunk, step slice) of the ticket it draws.  A chain's step count runs over the
+    // launch's steps [s_begin, n_steps): counters of the stream and retained rows need nothing else.
+    constexpr int kChunk = screen_parks<D, TP>() ? 2 * kBlock : kBlock;  // chains per workgroup
+    __shared__ uint32_t sched_word[4];
+    const bool sliced = a.sched != nullptr && (int32_t)blockIdx.x >= a.sched_first;
+    uint32_t chunk = blockIdx.x;
+    int32_t s_begin = 0, n_steps = (int32_t)a.n_steps;
+    bool timed_out = false;
+    if (sliced) {
+        int32_t len;
+        if (!SliceSched::take(a, kChunk, sched_word, chunk, s_begin, len, timed_out)) return;  // (one ticket per workgroup: never)
+        n_steps = s_begin + len;
+    }
     const bool shrink = a.sampler == GSSS_SHRINK;
     const int32_t thin = (int32_t)a.thin;
     const double rcp_thin = 1.0 / (double)thin;  // (compact chains: the retained row follows from the step count)
@@ -673,7 +686,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
     constexpr bool kPark = screen_parks<D, TP>();
     constexpr int kPerBlock = kPark ? 2 * kBlock : kBlock;
-    const int32_t id0 = (int32_t)blockIdx.x * kPerBlock + (int32_t)threadIdx.x;
+    const int32_t id0 = (int32_t)chunk * kPerBlock + (int32_t)threadIdx.x;
     const int32_t id1 = id0 + kBlock;
 
     Chain cur;
@@ -714,12 +727,19 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
         for (int i = 0; i < Chain::kQ; ++i) cur.q[i] = 0.0f;
         cur.lo = cur.hi = cur.thr = 0.0;
         cur.n_try = 0u;
-        cur.steps_done = 0;
-        cur.row = 0;
+        cur.steps_done = s_begin;
+        cur.row = s_begin / thin;
         cur.err = 0;
         cur.cursor = 0;
         cur.t = 0;
-        cur.status = (valid && n_steps > 0) ? kPending : kDone;
+        cur.status = (valid && n_steps > s_begin) ? kPending : kDone;
+        if (sliced && valid) {
+            if (SliceSched::dead(a, kChunk)[cc] != 0) cur.status = kDone;  // stopped with an error flag in an earlier slice
+            if (timed_out && cur.status != kDone) {                             // cannot happen (SliceSched::take)
+                cur.err |= GSSS_CHAIN_MAX_TRIES | GSSS_CHAIN_COUNTER_SATURATED;
+                cur.status = kDone;
+            }
+        }
     };
 
     // everything a step needs before its first try (mcmc.py:387-392); arithmetic identical to fast_kernel's
@@ -934,9 +954,10 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
         if (c >= n) return;
 #pragma unroll
         for (int j = 0; j < D; ++j) a.state[(size_t)j * n + c] = cur.x[j];
-        if (a.n_reject) a.n_reject[c] += (int64_t)cur.n_try - cur.steps_done;
+        if (a.n_reject) a.n_reject[c] += (int64_t)cur.n_try - (cur.steps_done - s_begin);
         if (a.n_tries) a.n_tries[c] += (int64_t)cur.n_try;
         if (a.err && cur.err) a.err[c] |= cur.err;
+        if (sliced && cur.steps_done < n_steps) SliceSched::dead(a, kChunk)[c] = 1;  // stopped early: stays stopped
     };
 
     if (kPark) {  // the chain of slot 1 is initialised, set up and parked; then the chain of slot 0
@@ -1011,6 +1032,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
         trade();
         flush();
     }
+    if (sliced) SliceSched::publish(a, sched_word);
 }
 
 template <int D, class TP, bool REPLAY>
@@ -1030,14 +1052,23 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
         }
     }
     const int per_block = screen_parks<D, TP>() ? 2 * kBlock : kBlock;
-    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
+    const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
+    // a small last round of workgroups is cut into step slices (plan_partial_round, gsss_device.h)
+    int32_t first = 0;
+    const SlicePlan plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>(), st, first);
+    RunBlock rbl = rb;
+    rbl.sched = plan.ws;
+    rbl.slice_steps = plan.slice_steps;
+    rbl.sched_first = first;
+    const int64_t grid = plan.grid;
     if (getenv("GSSS_DEBUG_OCCUPANCY")) {  // (tuning aid: what the runtime says about residency)
         int per_cu = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds);
         fprintf(stderr, "gsss: screened kernel: %zu B of LDS per workgroup, %d workgroups per CU, grid %lld\n", lds, per_cu, (long long)grid);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rbl);
     hipError_t e = hipGetLastError();
+    if (plan.ws) (void)hipFreeAsync(plan.ws, st);
     if (e != hipSuccess) {
         set_error("screened kernel launch failed: %s", hipGetErrorString(e));
         return GSSS_E_HIP;

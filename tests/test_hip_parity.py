@@ -807,3 +807,36 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
         assert 0 < int((err != 0).sum()) < n_chains               # stopped chains and healthy ones, both kinds in every slice
     else:
         assert int((err != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1024), ("vmfmix_k10_kappa500", 768), ("bingham_d10_vmax30", 768),
+                                           ("vmfmix_d10_k5_kappa100", 512)])
+def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, monkeypatch):
+    """The lane kernels (two chains per lane) cut only a SMALL last round of workgroups into step slices
+    (plan_partial_round, gsss_device.h): an ensemble of k x resident + a few workgroups gives the same bits -- states,
+    retained rows, tries, rejections, error flags -- sliced or not, and a chain that stops in one slice stays stopped."""
+    import torch
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    n_chains = (resident + 37) * 512 - 100                      # one full round of workgroups + 37 more, the last one ragged
+    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=43).T
+    out = {}
+    for label, env in (("whole", "0"), ("sliced", "128")):
+        monkeypatch.setenv("GSSS_SLICE_STEPS", env)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=6, mode="fast", placement="packed", step_offset=91, max_tries=24)
+        assert _packed_kernel(s).startswith("screened_kernel")
+        kept = [s.advance(m, thin=13) for m in (650, 520)]
+        import ctypes as C
+        grid, steps = C.c_int64(0), C.c_int32(0)
+        s._lib.gsss_last_launch(C.byref(grid), C.byref(steps))
+        out[label] = (s.state_device.clone(), torch.cat(kept), s._n_tries.clone(), s._n_reject.clone(), s._err.clone(), int(steps.value))
+    assert out["whole"][5] == 0
+    if out["sliced"][5] == 0:
+        pytest.skip("this box holds another number of workgroups of this kernel: nothing was sliced")
+    err = out["whole"][4]
+    ok = err == 0
+    for i in (0, 2, 3, 4):
+        assert torch.equal(out["whole"][i], out["sliced"][i]), i
+    assert torch.equal(out["whole"][1][:, :, ok], out["sliced"][1][:, :, ok])
+    assert 0 < int((err != 0).sum()) < n_chains
