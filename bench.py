@@ -113,7 +113,7 @@ def stream_description(d):
     return STREAM_S2 if d == 3 else STREAM_D
 
 
-def issue_counters(workload, n, S, thin, mode):
+def issue_counters(workload, n, S, thin, mode, layout="chains"):
     """Issue-side counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools/pmc_traffic.py), quoted only when this run's launch has the profiled shape: how busy the vector pipes were, how many
     wavefronts were resident, and the FP64 flops the kernel actually ISSUED against the FP64 peak."""
@@ -122,12 +122,12 @@ def issue_counters(workload, n, S, thin, mode):
     except (OSError, KeyError, ValueError):
         return {}
     shape = rec.get("launch", {})
-    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode")) != (n, S, thin, mode):
+    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode"), shape.get("layout", "components")) != (n, S, thin, mode, layout):
         return {}
     return dict(rec.get("issue", {}))
 
 
-def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms):
+def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms, layout="chains"):
     """Delivered-work figure: the FP64 flops of the ALL-DOUBLE restricted-form algorithm whose decisions the kernel reproduces
     (algorithmic_flops) over the kernel time and the FP64 vector peak.  NOT a hardware utilisation: most per-try flops are
     executed in single precision; `fp64_issued_frac` and `valu_busy` are the hardware's own counters."""
@@ -136,7 +136,7 @@ def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms):
            "frac": flops * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "flops_per_chain_step": flops,
            "meaning": "algorithmic FP64 flops of the all-double algorithm / kernel time / FP64 vector peak: delivered work, not "
                       "hardware utilisation (see fp64_issued_frac, valu_busy)"}
-    iss = issue_counters(name, n, S, thin, mode)
+    iss = issue_counters(name, n, S, thin, mode, layout)
     for k in ("fp64_issued_frac", "valu_busy", "resident_waves_per_simd", "valu_insts_per_chain_step", "lane_activity"):
         out[k] = iss.get(k)
     out["counters_source"] = iss.get("source")
@@ -224,7 +224,7 @@ def ess_per_sec(gs, sampler, pdf, steps_per_sec_total, n_steps=4000, thin=4, lag
     return out
 
 
-def measured_traffic(workload, n, S, thin, mode):
+def measured_traffic(workload, n, S, thin, mode, layout="chains"):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); only quoted when this
     run's launch has the shape the profile was taken with."""
@@ -233,7 +233,7 @@ def measured_traffic(workload, n, S, thin, mode):
     except (OSError, KeyError, ValueError):
         return None, None
     shape = rec.get("launch", {})
-    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode")) != (n, S, thin, mode):
+    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode"), shape.get("layout", "components")) != (n, S, thin, mode, layout):
         return None, None
     return rec["bytes_per_launch"], rec["source"]
 
@@ -270,13 +270,38 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def time_config(gs, torch, name, n, S, seed=3521, ess=True):
+def pick_layout(layout, kernel_name, d):
+    """--layout auto: the layout that moves the fewest bytes for the kernel family (measured, tools/layout_experiment.sh; both are
+    what the C ABI offers, gsss_run_args.samples_chain_rows).  The group kernels step a wavefront's chains together, so a kept
+    row leaves as whole 512-byte runs per component: component-major.  The lane kernels keep a chain's row when ITS step count
+    says so: 8-byte stores into eight chains' shared 64-byte lines at different times (WRITE_SIZE 2.6 GB for the 0.8 GB of
+    kept rows of Bingham d = 10); chain-major, a chain's 8 d bytes are contiguous and leave together (1.2 GB) -- unless a row is
+    smaller than a line (d = 3: 24 bytes; chain-major 0.55 GB against 0.29 GB)."""
+    if layout != "auto":
+        return layout
+    lane = kernel_name.startswith(("screened_kernel", "fast_kernel"))
+    return "chains" if lane and 8 * d >= 64 else "components"
+
+
+def kept_buffer(torch, layout, n, S, thin, d):
+    """Where the retained rows of one launch go.  "chains": (chains, draws, dims), the reference's own order (what
+    `sampler.sample()` returns; a chain appends its 8 d bytes per kept row to its own run) -- "components": [row][d][chain], the
+    kernels' component-major state layout."""
+    if layout == "chains":
+        return torch.empty((n, S // thin, d), dtype=torch.float64, device="cuda"), dict(chain_major=True, row0=0)
+    return torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda"), dict()
+
+
+def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
     """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload."""
     pdf, d = make_target(gs, name)
     x0 = gs.sample_sphere_device(d - 1, n, seed=0)
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed)
     thin = 100
-    kept = torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda")
+    lib = gs._lib.load()
+    mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
+    layout = pick_layout(layout, lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(), d)
+    kept, kw = kept_buffer(torch, layout, n, S, thin, d)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     s.advance(100)                                   # warm-up: 100 transitions (cfg: "warm-up 100 steps")
@@ -289,7 +314,7 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True):
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
-        s.advance(S, thin=thin, out=kept)
+        s.advance(S, thin=thin, out=kept, **kw)
         b.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -299,7 +324,7 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True):
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
     slice_steps = last_slice_steps(gs)
     bytes_launch = hbm_bytes_per_step(d, thin, S, slice_steps) * n * S
-    traffic, src = measured_traffic(name, n, S, thin, s.mode)
+    traffic, src = measured_traffic(name, n, S, thin, s.mode, layout)
     value = n * S * reps / dt
     # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
     # (the curve targets mix over hundreds of steps: thin 32, so that the 64 lags span 2048 steps)
@@ -313,7 +338,8 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True):
             "roofline": {"bound": "hbm", "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": src},
-            "roofline_valu": roofline_valu(name, d, tps, n, S, thin, s.mode, kern_ms)}
+            "kept_rows_layout": layout,
+            "roofline_valu": roofline_valu(name, d, tps, n, S, thin, s.mode, kern_ms, layout)}
 
 
 def main(argv=None):
@@ -328,6 +354,9 @@ def main(argv=None):
     ap.add_argument("--thin", type=int, default=100, help="keep every thin-th state (cfg2: every 100th)")
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--layout", default="auto", choices=["auto", "chains", "components"],
+                    help="retained rows: (chains, draws, dims) as the reference returns them, the kernels' [row][d][chain], or "
+                         "(auto) whichever moves fewer bytes for the kernel family, see pick_layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
@@ -383,7 +412,9 @@ def main(argv=None):
                                                 variant=args.variant)
     S = args.inner
     thin = min(args.thin, S) if args.thin > 0 else S
-    kept = torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda")
+    args.layout = pick_layout(args.layout, gs._lib.load().gsss_kernel_name(
+        sampler._target_dev.handle, gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT, args.variant, 1).decode(), d)
+    kept, kw = kept_buffer(torch, args.layout, n, S, thin, d)
     counts = [n] * world                             # chains per rank are fixed: no size exchange per gather
 
     def barrier():
@@ -393,7 +424,7 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sampler.advance(S, thin=thin, out=kept)
+        sampler.advance(S, thin=thin, out=kept, **kw)
     rccl = {"ranks_seen": 1, "backend": None, "gather_ms": 0.0}
     if world > 1:  # the collective's lazy channel setup must not land inside the timed region
         gather_states(sampler.state_device, counts=counts)
@@ -413,7 +444,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
-        sampler.advance(S, thin=thin, out=kept)
+        sampler.advance(S, thin=thin, out=kept, **kw)
         b.record()
     final = gather_states(sampler.state_device, counts=counts) if world > 1 else sampler.state_device
     barrier()
@@ -449,7 +480,7 @@ def main(argv=None):
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
-        traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode)
+        traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode, args.layout)
         out = {
             "metric": "mcmc_chain_steps_per_sec", "value": value, "unit": "chain-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -458,6 +489,7 @@ def main(argv=None):
                                    "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
                        "stream": stream_description(d),
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
+                       "kept_rows_layout": args.layout,
                        "mode": sampler.mode,
                        "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
                        "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"
@@ -469,13 +501,13 @@ def main(argv=None):
                          "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                  "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
                                  "issue (see roofline_valu and DESIGN.md)"},
-            "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms),
+            "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms, args.layout),
         }
         if world == 1 and not args.no_ess:
             out["ess"] = ess_per_sec(gs, sampler, pdf, value)
         if world == 1 and not args.no_configs and args.workload == "vmfmix_readme":
             del sampler, kept
-            out["configs"] = [time_config(gs, torch, name, nc, S) for name, nc in EXTRA_CONFIGS]
+            out["configs"] = [time_config(gs, torch, name, nc, S, layout=args.layout) for name, nc in EXTRA_CONFIGS]
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

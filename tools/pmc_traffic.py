@@ -47,7 +47,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
     out[wl] = {"kernel": name.split("(")[0].replace("void ", ""), "fetch_size_kib": fetch, "write_size_kib": write,
                "bytes_per_launch": (2 * fetch + write) * 1024.0,
                "launch": {"chains": cfg.get("chains_per_gpu"), "steps": cfg.get("transitions_per_step"), "thin": thin,
-                          "mode": cfg.get("mode")},
+                          "mode": cfg.get("mode"), "layout": cfg.get("kept_rows_layout", "components")},
                "source": f"profiles/{tag}_{wl}_summary.md (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes)"}
     # issue side of the same kernel (passes sq1 / sq2 / sq3 of tools/collect_profiles.sh): what bench.py quotes next to
     # roofline_valu so that the delivered-work fraction is never read as a hardware utilisation
