@@ -412,9 +412,9 @@ def main(argv=None):
                                                 variant=args.variant)
     S = args.inner
     thin = min(args.thin, S) if args.thin > 0 else S
-    args.layout = pick_layout(args.layout, gs._lib.load().gsss_kernel_name(
+    layout = pick_layout(args.layout, gs._lib.load().gsss_kernel_name(
         sampler._target_dev.handle, gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT, args.variant, 1).decode(), d)
-    kept, kw = kept_buffer(torch, args.layout, n, S, thin, d)
+    kept, kw = kept_buffer(torch, layout, n, S, thin, d)
     counts = [n] * world                             # chains per rank are fixed: no size exchange per gather
 
     def barrier():
@@ -480,7 +480,7 @@ def main(argv=None):
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
-        traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode, args.layout)
+        traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode, layout)
         out = {
             "metric": "mcmc_chain_steps_per_sec", "value": value, "unit": "chain-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -489,7 +489,7 @@ def main(argv=None):
                                    "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
                        "stream": stream_description(d),
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
-                       "kept_rows_layout": args.layout,
+                       "kept_rows_layout": layout,
                        "mode": sampler.mode,
                        "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
                        "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"
@@ -501,7 +501,7 @@ def main(argv=None):
                          "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                  "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
                                  "issue (see roofline_valu and DESIGN.md)"},
-            "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms, args.layout),
+            "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms, layout),
         }
         if world == 1 and not args.no_ess:
             out["ess"] = ess_per_sec(gs, sampler, pdf, value)
