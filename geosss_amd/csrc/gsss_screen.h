@@ -25,6 +25,10 @@
 #pragma once
 #include "gsss_fast.h"
 
+#ifndef GSSS_SCREEN_REGEN_THR
+#define GSSS_SCREEN_REGEN_THR 1  // (A/B: 0 parks the threshold uniform of the S^2 mixtures as round 2 did)
+#endif
+
 namespace gsss {
 
 // A try that stopped: accepted for sure / double precision decides.  Its theta rests in the end of the bracket it would
@@ -84,12 +88,16 @@ struct ScreenVmf : FastVmf<D, KC> {
     // 18 instead of 28 words of parked state at K = 10, three workgroups per CU instead of two (and the register budget
     // of three wavefronts per SIMD asked of the compiler: 170 -> 168)
     static constexpr int kParkSkip = KC >= 6 ? 2 * KC : 0;  // (K = 3: 36.5 against 34.8 ms with it -- four workgroups per CU fit anyway)
-    static constexpr int kMinWaves = KC >= 6 ? 3 : 1;
+    static constexpr int kMinWaves = KC >= 6 ? 3 : ((GSSS_SCREEN_REGEN_THR && D == 3 && KC <= 3) ? 5 : 1);
     // K >= 6 forms the 2 K coefficients again at take-up (kParkSkip), which makes a swap as dear as a pair of tries: swapping only
     // when 24 lanes want to is worth 9 % (K = 10, kappa = 500: 56.6 -> 51.7 ms per 10^9 chain-steps; 12: 52.5, 32: 59.2, 44: 71.7);
     // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
     static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
     static constexpr bool kCompact = false;
+    // S^2, K <= 3 (the README target, BASELINE cfg2): the threshold uniform is not parked -- an undecided try draws it again
+    // from the counter-based stream -- which makes the parked state 15 words: five workgroups per CU instead of four (the
+    // kernel needs 95 registers: five wavefronts per SIMD fit)
+    static constexpr bool kRegenThr = GSSS_SCREEN_REGEN_THR && D == 3 && KC <= 3;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&x)[D], const double (&u)[D], float (&q)[kCoef32Floats]) const
     {
@@ -217,7 +225,7 @@ struct ScreenBingham : FastBingham<D> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 6;
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
-    static constexpr bool kCompact = false;
+    static constexpr bool kCompact = false, kRegenThr = false;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
@@ -289,7 +297,7 @@ struct ScreenBinghamDiag {
     static constexpr bool kLinear = false;
     static constexpr int kCoef32Floats = 4;  // q0 = -log U, q1 = qxu, q2 = (quu - qxx) - log U | margin
     static constexpr int kParkSkip = 0, kMinWaves = D >= 9 ? 3 : 1, kTradeMin = 1;
-    static constexpr bool kCompact = true;
+    static constexpr bool kCompact = true, kRegenThr = true;
     const double *a;  // LDS [D]: the diagonal of A
     struct Coef {
         double qxx, qxu, quu;
@@ -492,7 +500,7 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
-    static constexpr bool kCompact = false;
+    static constexpr bool kCompact = false, kRegenThr = false;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     Curve32<NK> c32;
@@ -598,9 +606,10 @@ struct ScreenChain {
     // (TP::retail), the threshold uniform is drawn again for an undecided try (not from a replayed stream: there it is parked)
     // and the retained row follows from the step count -- x, u, lo, hi | q0 q1 | q2 steps_done | n_try flags.
     static constexpr bool kCompact = TP::kCompact;
-    static_assert(!kCompact || (TP::kCoef32Floats == 4 && kSkip == 0), "compact layout: three parked floats");
-    static constexpr int kWordsNoReplay = kCompact ? 2 * D + 2 + 3 : 2 * D + 3 + (kQ - kSkip) / 2 + 2;
-    static constexpr int kWords = kWordsNoReplay + (kCompact ? 2 : 1);  // replay: + the cursor (compact: + the threshold uniform)
+    static constexpr bool kRegenThr = TP::kRegenThr;  // the threshold uniform is parked only with a replayed stream
+    static_assert(!kCompact || (TP::kCoef32Floats == 4 && kSkip == 0 && kRegenThr), "compact layout: three parked floats");
+    static constexpr int kWordsNoReplay = kCompact ? 2 * D + 2 + 3 : 2 * D + 2 + (kRegenThr ? 0 : 1) + (kQ - kSkip) / 2 + 2;
+    static constexpr int kWords = kWordsNoReplay + 1 + (kRegenThr ? 1 : 0);  // replay: + the cursor (+ the threshold uniform)
 };
 
 template <int D, class TP>
@@ -652,7 +661,7 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
 
 // (measured: asking for two wavefronts per SIMD at d = 10 makes the curve kernel spill 73 registers: 45 -> 64 ms)
 template <int D, class TP, bool REPLAY, bool STATS = false>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
     using Chain = ScreenChain<D, TP>;
@@ -857,7 +866,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
         bool accepted = true;
         if (is_decide(cur.status)) {  // rare: the double-precision test itself (mcmc.py:389, 397)
             double u_thr = cur.thr;
-            if constexpr (Chain::kCompact && !REPLAY) {  // not parked: the step's threshold uniform, drawn again
+            if constexpr (Chain::kRegenThr && !REPLAY) {  // not parked: the step's threshold uniform, drawn again
                 double u_th0;
                 if constexpr (D == 3) {
                     uint32_t w_phi;
@@ -920,7 +929,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
             lds_trade(cur.q[2], cur.steps_done, p);
             p += kBlock;
         } else {
-            word(cur.thr);
+            if (!Chain::kRegenThr || REPLAY) word(cur.thr);
 #pragma unroll
             for (int i = Chain::kSkip; i < Chain::kQ; i += 2) {
                 lds_trade(cur.q[i], cur.q[i + 1], p);
@@ -984,7 +993,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : TP::kMinWaves) screened_ke
             put2(__float_as_uint(cur.q[0]), __float_as_uint(cur.q[1]));
             put2(__float_as_uint(cur.q[2]), (uint32_t)cur.steps_done);
         } else {
-            put(cur.thr);
+            if (!Chain::kRegenThr || REPLAY) put(cur.thr);
 #pragma unroll
             for (int i = Chain::kSkip; i < Chain::kQ; i += 2) put2(__float_as_uint(cur.q[i]), __float_as_uint(cur.q[i + 1]));
             put2((uint32_t)cur.steps_done, (uint32_t)cur.row);
