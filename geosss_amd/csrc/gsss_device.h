@@ -214,7 +214,7 @@ inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock 
     const char *env = getenv("GSSS_SLICE_STEPS");
     const int env_val = env ? atoi(env) : 128;
     const int env_steps = env_val > 0 ? ((env_val + 63) / 64) * 64 : 0;
-    if (env_steps <= 0 || rb.n_steps < 4 * (int64_t)env_steps) return p;
+    if (env_steps <= 0 || rb.n_steps < 2 * (int64_t)env_steps) return p;
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
         hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {

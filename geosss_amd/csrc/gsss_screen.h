@@ -1024,7 +1024,16 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         const int n_live = __popcll(live);
         // the service phase (double precision) costs several try iterations (single precision): it runs when three
         // quarters of the live lanes wait for it (or seven eighths have something for it)
-        const bool service = pend != 0ull && (4 * __popcll(waiting) >= 3 * n_live || 8 * __popcll(pend) >= 7 * n_live);
+#ifndef GSSS_SVC_WAIT_NUM
+#define GSSS_SVC_WAIT_NUM 3
+#define GSSS_SVC_WAIT_DEN 4
+#endif
+#ifndef GSSS_SVC_PEND_NUM
+#define GSSS_SVC_PEND_NUM 7
+#define GSSS_SVC_PEND_DEN 8
+#endif
+        const bool service = pend != 0ull && (GSSS_SVC_WAIT_DEN * __popcll(waiting) >= GSSS_SVC_WAIT_NUM * n_live ||
+                                              GSSS_SVC_PEND_DEN * __popcll(pend) >= GSSS_SVC_PEND_NUM * n_live);
         if (service) {
             if (kPark && !needs_service(cur.status) && needs_service(parked_status)) trade();  // bring the waiting chain in
             if (is_final(cur.status)) finalise();
