@@ -840,3 +840,25 @@ def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, monkeypatc
         assert torch.equal(out["whole"][i], out["sliced"][i]), i
     assert torch.equal(out["whole"][1][:, :, ok], out["sliced"][1][:, :, ok])
     assert 0 < int((err != 0).sum()) < n_chains
+
+
+def test_sliced_launch_long_hand_over_chain(gs, monkeypatch):
+    """The bench's own launch shape -- 10^5 curve chains x 1000 steps, 1563 chunks x 16 slices of 64 steps, every chunk handed from
+    CU to CU (and XCD to XCD) fifteen times -- against the unsliced launch: every state bit, every counter.  A stale line
+    anywhere along a hand-over chain would show here."""
+    import torch
+    z = golden("traj_curve_d10_kappa800.npz")
+    pdf = product_target(z)
+    n = 100_000
+    x0 = gs.sample_sphere_device(9, n, seed=47).T
+    out = {}
+    for label, env in (("whole", "0"), ("s64", "64"), ("s128", "128")):
+        monkeypatch.setenv("GSSS_SLICE_STEPS", env)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=8, mode="fast", placement="packed")
+        kept = s.advance(1000, thin=100)
+        s.advance(1000)
+        out[label] = (s.state_device.clone(), kept.clone(), s._n_tries.clone(), s._n_reject.clone(), s._err.clone())
+    for label in ("s64", "s128"):
+        for i in range(5):
+            assert torch.equal(out["whole"][i], out[label][i]), (label, i)
+    assert int((out["whole"][4] != 0).sum()) == 0
