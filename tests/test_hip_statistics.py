@@ -142,21 +142,6 @@ def test_eight_million_chains_one_gpu(gs):
     assert s.state_device.shape == (3, n)
 
 
-def test_ess_matches_reference_estimate(gs):
-    """ESS per step on the README target with the reference's IAT estimator: mean over 512 GPU chains vs
-    the reference chain of tests/golden/diagnostics_kat.npz (one chain: loose tolerance)."""
-    z, k = golden("traj_vmfmix_readme.npz"), golden("diagnostics_kat.npz")
-    pdf = product_target(z)
-    x0 = gs.sample_sphere_device(2, 512, seed=2).T
-    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=8)
-    s.advance(500)
-    X = s.sample(4001, as_tensor=True)
-    iat = gs.diagnostics.IAT(X.permute(0, 2, 1).contiguous())          # (chains, dims)
-    ours = 1.0 / iat.mean(0).cpu().numpy()
-    ref = 1.0 / k["vmf_IAT"]
-    assert np.all(ours / ref > 0.5) and np.all(ours / ref < 2.0), (ours, ref)
-
-
 def test_extreme_concentration_is_handled(gs, oracle):
     """kappa = 2000 (> 714, where the reference's log(i0(kappa)) overflows and its sampler never returns):
     both kernel families run without error flags, agree with each other, and the chains find the modes."""
@@ -176,18 +161,19 @@ def test_extreme_concentration_is_handled(gs, oracle):
 
 
 def test_bingham_mixing_matches_reference(gs):
-    """Bingham d=10 (scripts/bingham.py): IAT per coordinate and the hopping frequency between the two
-    antipodal modes, 512 GPU chains against the reference chain of diagnostics_kat.npz."""
+    """Bingham d=10 (scripts/bingham.py): the hopping frequency between the two antipodal modes, 512 GPU chains against the
+    reference chain of diagnostics_kat.npz (four standard errors of that one chain's estimate + 5 %)."""
     z, k = golden("traj_bingham_d10_vmax30.npz"), golden("diagnostics_kat.npz")
     pdf = product_target(z)
     s = gs.ShrinkageSphericalSliceSampler(pdf, np.repeat(z["x0"][None], 512, axis=0), seed=12)
     s.advance(500)
     X = s.sample(3000, as_tensor=True)                                   # (chains, draws, dims)
-    iat = gs.diagnostics.IAT(X.permute(0, 2, 1).contiguous()).mean(0).cpu().numpy()
-    ratio = iat / k["bingham_IAT"]
-    assert np.all(ratio > 0.4) and np.all(ratio < 2.5), ratio
+    # (the integrated autocorrelation times are held to the reference's by the z-test below -- 8 reference chains -- and the
+    # paper's relative bulk ESS by test_published_relative_bulk_ess_of_the_bingham_experiment; round 2's 0.4 .. 2.5 x band against
+    # ONE reference chain is gone)
     hop = float(gs.diagnostics.hopping_frequency(X, k["bingham_mode"]).mean())
-    assert abs(hop - float(k["bingham_hop"])) < 0.35 * float(k["bingham_hop"]) + 0.002, (hop, float(k["bingham_hop"]))
+    ref = float(k["bingham_hop"])                       # one reference chain of 3000 draws: binomial noise sqrt(p / 3000)
+    assert abs(hop - ref) < 4.0 * np.sqrt(ref / 3000.0) + 0.05 * ref, (hop, ref)
 
 
 def test_bingham_d50_geodesic_step(gs):
