@@ -55,33 +55,11 @@ __host__ __device__ constexpr size_t curvespec_lds_doubles()
            (Q >= 2 ? (size_t)4 * Q * kBlock : 0);  // Q >= 2: the tangent u rests in LDS while the tries run
 }
 
-// The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397),
-// FastCurve::level operation for operation, from the step's coefficients parked in LDS (coef[0 .. NK) = a_i.x,
-// coef[NK .. 2 NK) = a_i.u), segment by segment in a rolled loop.  (Inlined on purpose: as a called function it takes the
-// tables and segment constants through generic pointers, and every table read of the kernel becomes a flat_load.)
-template <int NK>
-__device__ __forceinline__ bool curvespec_decide(const FastCurve<1, NK> &scl, const double *coef, const fm::Tables &tab, double theta,
-                                              double u_thr)
-{
-    double sn, cs;
-    fm::sincos_tab(theta, tab, sn, cs);
-    double best0 = -INFINITY, dot0 = 0.0, best1 = -INFINITY, dot1 = 0.0;
-    double cx = coef[0], cu = coef[NK];
-    double ay0 = fma(1.0, cx, 0.0 * cu), ay1 = fma(cs, cx, sn * cu);
-#pragma unroll 1
-    for (int gg = 0; gg + 1 < NK; ++gg) {
-        cx = coef[gg + 1];
-        cu = coef[NK + gg + 1];
-        const double by0 = fma(1.0, cx, 0.0 * cu), by1 = fma(cs, cx, sn * cu);
-        scl.segment(gg, ay0, by0, best0, dot0);
-        scl.segment(gg, ay1, by1, best1, dot1);
-        ay0 = by0;
-        ay1 = by1;
-    }
-    return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
-}
-
-// The same decision taken by the GROUP (round 3): lane g evaluates segments g, g + L, ... at theta = 0 and at theta, a DPP
+// The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397), FastCurve::level
+// operation for operation, from the step's double-precision coefficients parked in the group's LDS words: coef[2 i] = a_i.x,
+// coef[2 i + 1] = a_i.u.  (Inlined on purpose: as a called function it takes the tables and segment constants through generic
+// pointers, and every table read of the kernel becomes a flat_load.)
+// Taken by the GROUP (round 3; round 2: by the one lane of the try, segment after segment): lane g evaluates segments g, g + L, ... at theta = 0 and at theta, a DPP
 // butterfly over the group picks the first segment of maximal clipped value for each -- (value, index) is totally ordered
 // (larger value first, then smaller index), so the winner is the one the sequential scan keeps, and the comparison at the
 // end is formed from the same bits.  An undecided try costs 3 rolled iterations (NK = 10, L = 4) instead of 9 with the other
@@ -97,7 +75,7 @@ __device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &s
     int idx0 = NK, idx1 = NK;
 #pragma unroll 1
     for (int gg = g; gg + 1 < NK; gg += L) {
-        const double cxa = coef[gg], cua = coef[NK + gg], cxb = coef[gg + 1], cub = coef[NK + gg + 1];
+        const double cxa = coef[2 * gg], cua = coef[2 * gg + 1], cxb = coef[2 * gg + 2], cub = coef[2 * gg + 3];
         const double ay0 = fma(1.0, cxa, 0.0 * cua), by0 = fma(1.0, cxb, 0.0 * cub);
         const double ay1 = fma(cs, cxa, sn * cua), by1 = fma(cs, cxb, sn * cub);
         double xc, xy;
@@ -160,7 +138,9 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     if (kSlotMajor) {
         for (int j = threadIdx.x; j < NK * DPAD; j += kBlock) {
             const int r = j / DPAD, w = j - r * DPAD;
-            const int c = V::comp(w % L, w / L);
+            // (round 3: slot PAIRS -- slots 2 p, 2 p + 1 of lane g at words 2 (p L + g), 2 (p L + g) + 1: the same conflict-free
+            // broadcast pattern with 16-byte reads, half the LDS instructions)
+            const int c = V::comp((w / 2) % L, 2 * ((w / 2) / L) + (w & 1));
             lds[j] = (r < k && c < d) ? tb.blob[(size_t)r * d + c] : 0.0;
         }
     } else {
@@ -180,12 +160,12 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     c32.stage(reinterpret_cast<float4 *>(sg + 4 * (NK - 1)), sg, k - 1, tb.kappa);
     double *scr = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (threadIdx.x / L);
     double *ring = scr + 2;
-    double *coef = ring + kRing;  // [2 NK]: a_i.x | a_i.u of the step (for the double-precision decisions)
+    double *coef = ring + kRing;  // [NK][2]: a_i.x, a_i.u of the step (for the double-precision decisions), 16-byte aligned
     const fm::Tables tab = stage_tables(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L));
     // Q >= 2 (d > 64): u is only needed again when the chain moves; its 8 Q registers are lent to the try loop meanwhile
-    // (slot i of thread t at [i][t]: conflict-free)
+    // (slots 2 p, 2 p + 1 of thread t at [p][t][2]: 16-byte accesses, conflict-free)
     constexpr bool kParkU = Q >= 2;
-    double *upark = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2 + threadIdx.x;
+    double2 *upark = reinterpret_cast<double2 *>(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2) + threadIdx.x;
     Scalar sc;
     sc.knots = lds;
     sc.seg = sg;
@@ -227,7 +207,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     const double *rp = REPLAY ? a.replay + (size_t)c * a.replay_stride : nullptr;
     int64_t cursor = 0;
     int err = 0;
-    // (kRecur: a_i . x is carried from step to step in the group's LDS words coef[0 .. NK), advanced by lane 0)
+    // (kRecur: a_i . x is carried from step to step in the group's LDS words coef[2 i], advanced by lane 0)
     float lvl_c = 0.0f, e_c = 0.0f;  // single-precision level of the accepted point and its error bound, carried to the next step
     int64_t n_try = 0;
     // (a chain that is alive has made every step so far: retained rows follow from the slice's first step)
@@ -265,7 +245,8 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         // in registers for the whole launch: the base is made opaque once per step.
         unsigned opaque = 0u;
         asm volatile("" : "+s"(opaque));
-        const double *knots = lds + opaque;  // (an offset, so that the pointer stays an LDS pointer: ds_read, not flat_load)
+        // (an offset, so that the pointer stays an LDS pointer: ds_read, not flat_load)
+        const double *knots = lds + opaque;
         Scalar scl = sc;
         scl.seg = knots + (size_t)NK * DPAD;
         Curve32<NK> c32s = c32;
@@ -325,9 +306,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
                 publish_extra(g, w);
                 pref = 2 * (L - 1);
             }
-            wave_sync();
-            u_thr = scr[0];
-            u_th0 = scr[1];
+            u_thr = u_th0 = 0.0;  // (published to the group's LDS words: read behind the wave_sync that follows the knot dots)
         }
         // ---------------- u = spherical_projection(z, x)   (sphere.py:29-33)
         const double xx = vdot<V>(x, x);
@@ -347,31 +326,54 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
             for (int r = 0; r < NK; ++r) {
                 const double *row = knots + (size_t)r * DPAD;
                 double pu = 0.0, px = 0.0;
+                if constexpr (kSlotMajor) {
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const double kv = row[kSlotMajor ? i * L + g : V::comp(g, i)];
-                    pu = fma(kv, u[i], pu);
-                    if (refresh) px = fma(kv, x[i], px);
+                    for (int i = 0; i < N; i += 2) {
+                        const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
+                        pu = fma(kv.x, u[i], pu);
+                        if (refresh) px = fma(kv.x, x[i], px);
+                        pu = fma(kv.y, u[i + 1], pu);
+                        if (refresh) px = fma(kv.y, x[i + 1], px);
+                    }
+                } else {
+                    // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
+                    // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
+                    // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
+#pragma unroll
+                    for (int i = 0; i < N; i += 2) {
+                        const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
+                        pu = fma(kv.x, u[i], pu);
+                        if (refresh) px = fma(kv.x, x[i], px);
+                        pu = fma(kv.y, u[i + 1], pu);
+                        if (refresh) px = fma(kv.y, x[i + 1], px);
+                    }
                 }
                 const double au = group_sum<L>(pu) * rnw;
-                const double axr = refresh ? group_sum<L>(px) : coef[r];
+                const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
                 q[r] = (float)axr;
                 q[NK + r] = (float)au;
                 // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
                 // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
                 // the pair to one owner lane (round 2: 40 of the step's vector instructions)
-                coef[NK + r] = au;
-                if (refresh) coef[r] = axr;
+                if (refresh)
+                    *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
+                else
+                    coef[2 * r + 1] = au;
                 // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
                 if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
             }
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
+            for (int i = 0; i < N; i += 2) {
                 u[i] *= rnw;
-                if (kParkU) upark[(size_t)i * kBlock] = u[i];
+                u[i + 1] *= rnw;
+                if (kParkU) upark[(size_t)(i / 2) * kBlock] = make_double2(u[i], u[i + 1]);
             }
         }
-        wave_sync();
+        wave_sync();  // (one synchronisation for the step's uniforms, the parked coefficients and u)
+        if (!REPLAY) {
+            u_thr = scr[0];
+            u_th0 = scr[1];
+        }
         // threshold and margin (Curve32).  The level of x in single precision: the value the accepted try of the previous
         // step was screened with (it is within that step's evaluation error of the double-precision level of y(theta_T), which
         // IS the level of x now: the same operations on the same coefficients under the recurrence, and within ~1e-15 of
@@ -504,11 +506,20 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         double sn, cs;
         fm::sincos_tab(th_acc, tab, sn, cs);
         if (alive) {
+            if constexpr (kParkU) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = fma(sn, kParkU ? upark[(size_t)i * kBlock] : u[i], cs * x[i]);
+                for (int i = 0; i < N; i += 2) {
+                    const double2 up = upark[(size_t)(i / 2) * kBlock];
+                    x[i] = fma(sn, up.x, cs * x[i]);
+                    x[i + 1] = fma(sn, up.y, cs * x[i + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
+            }
             if (kRecur && g == 0) {
 #pragma unroll
-                for (int r = 0; r < NK; ++r) coef[r] = fma(cs, coef[r], sn * coef[NK + r]);  // a . x' = c a.x + s a.u
+                for (int r = 0; r < NK; ++r) coef[2 * r] = fma(cs, coef[2 * r], sn * coef[2 * r + 1]);  // a . x' = c a.x + s a.u
             }
             ++steps_done;
             if ((a.samples != nullptr || STATS) && --until_keep == 0) {

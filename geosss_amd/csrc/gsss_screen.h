@@ -419,6 +419,10 @@ struct Curve32 {
             // where the callers have none to spare (measured, d = 10 / 50: 30.8 / 64.2 -> 29.8 / 60.9 ms)
             if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
+        if (PRELOAD) {  // (the unused fourth word counts as read: ds_read_b128, 4 LDS cycles a wavefront, instead of ds_read_b96, 8)
+#pragma unroll
+            for (int g = 0; g + 1 < NK; ++g) asm volatile("" ::"v"(pre[g].w));
+        }
         return fminf(best, 1.0f);  // (the reference clips every y . nearest to [-1, 1]; the maximum of unit vectors' dots is >= -1)
     }
     // error bound of one best32 evaluation with the coefficients q[0 .. 2 NK)
