@@ -238,19 +238,23 @@ def measured_traffic(workload, n, S, thin, mode, layout="chains"):
     return rec["bytes_per_launch"], rec["source"]
 
 
-def hbm_bytes_per_step(d, thin, S, slice_steps=0):
+def hbm_bytes_per_step(d, thin, S, slice_steps=0, sliced_fraction=1.0):
     """Algorithmic HBM bytes per chain-step: retained sample 8d/thin + state load and
-    store 16d/S + the two int64 counters read-modify-written per launch 32/S; a SLICED launch hands
-    state and counters over through HBM once per slice: S is then the slice length."""
-    return 8.0 * d / thin + (16.0 * d + 32.0) / (min(S, slice_steps) if slice_steps > 0 else S)
+    store 16d/S + the two int64 counters read-modify-written per launch 32/S; the SLICED share of a launch (DESIGN.md section
+    5.4: every chain of a group kernel, the last partial round of a lane kernel) hands state and counters over through HBM
+    once per slice: for that share S is the slice length."""
+    hand_over = 16.0 * d + 32.0
+    f = sliced_fraction if slice_steps > 0 else 0.0
+    return 8.0 * d / thin + (1.0 - f) * hand_over / S + f * hand_over / min(S, max(slice_steps, 1))
 
 
 def last_slice_steps(gs):
-    """Slice length of this thread's last sampler launch (0: unsliced), gsss_last_launch."""
+    """(slice length, share of the chains that ran sliced) of this thread's last sampler launch ((0, 0.0): unsliced),
+    gsss_last_launch."""
     import ctypes as C
-    grid, steps = C.c_int64(0), C.c_int32(0)
-    gs._lib.load().gsss_last_launch(C.byref(grid), C.byref(steps))
-    return int(steps.value)
+    grid, steps, frac = C.c_int64(0), C.c_int32(0), C.c_double(0.0)
+    gs._lib.load().gsss_last_launch(C.byref(grid), C.byref(steps), C.byref(frac))
+    return int(steps.value), float(frac.value)
 
 
 def free_port():
@@ -322,8 +326,8 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
     tps = (int(s._n_tries.sum().item()) - tries0) / (n * S * reps)
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
-    slice_steps = last_slice_steps(gs)
-    bytes_launch = hbm_bytes_per_step(d, thin, S, slice_steps) * n * S
+    slice_steps, sliced_frac = last_slice_steps(gs)
+    bytes_launch = hbm_bytes_per_step(d, thin, S, slice_steps, sliced_frac) * n * S
     traffic, src = measured_traffic(name, n, S, thin, s.mode, layout)
     value = n * S * reps / dt
     # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
@@ -331,7 +335,7 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
     ess_steps, ess_thin = (16384, 64) if name.startswith("curve") else ((2000, 8) if name.startswith("bingham") else (2000, 4))
     ess_out = ess_per_sec(gs, s, pdf, value, n_steps=ess_steps, thin=ess_thin) if ess else None
     return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}",
-            "stream": stream_description(d), "slice_steps": slice_steps,
+            "stream": stream_description(d), "slice_steps": slice_steps, "sliced_fraction": round(sliced_frac, 4),
             "value": value, "unit": "chain-steps/s", "launches": reps, "mode": s.mode, "ess": ess_out,
             "kernel": lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(),
             "kernel_ms": kern_ms, "tries_per_step": tps, "chains_in_error": int((s._err != 0).sum().item()),
@@ -475,8 +479,8 @@ def main(argv=None):
     value = total_steps / elapsed
 
     if rank == 0:
-        slice_steps = last_slice_steps(gs)
-        bytes_per_launch = hbm_bytes_per_step(d, thin, S, slice_steps) * n * S
+        slice_steps, sliced_frac = last_slice_steps(gs)
+        bytes_per_launch = hbm_bytes_per_step(d, thin, S, slice_steps, sliced_frac) * n * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
@@ -489,6 +493,7 @@ def main(argv=None):
                                    "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
                        "stream": stream_description(d),
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
+                       "sliced_fraction": round(sliced_frac, 4),
                        "kept_rows_layout": layout,
                        "mode": sampler.mode,
                        "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),

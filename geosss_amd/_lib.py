@@ -56,7 +56,7 @@ SIGNATURES = {
     "gsss_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsss_run": (C.c_int, [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]),
     "gsss_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    "gsss_last_launch": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "gsss_last_launch": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "gsss_mode_supported": (C.c_int, [C.c_void_p, C.c_int32]),
     "gsss_variant_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "gsss_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -19,7 +19,7 @@ namespace gsss {
 // ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static thread_local LaunchInfo g_last_launch = {0, 0};
+static thread_local LaunchInfo g_last_launch = {0, 0, 0.0};
 LaunchInfo &last_launch() { return g_last_launch; }
 
 void set_error(const char *fmt, ...)
@@ -511,7 +511,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("chain / step ids exceed the 48-bit counter space");
         return GSSS_E_INVALID;
     }
-    last_launch() = LaunchInfo{0, 0};
+    last_launch() = LaunchInfo{0, 0, 0.0};
     if (a->n_chains == 0) return GSSS_OK;
     if (!a->state_dev) {
         set_error("state_dev is null");
@@ -637,10 +637,11 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     return GSSS_E_INVALID;
 }
 
-int gsss_last_launch(int64_t *grid_out, int32_t *slice_steps_out)
+int gsss_last_launch(int64_t *grid_out, int32_t *slice_steps_out, double *sliced_fraction_out)
 {
     if (grid_out) *grid_out = last_launch().grid;
     if (slice_steps_out) *slice_steps_out = last_launch().slice_steps;
+    if (sliced_fraction_out) *sliced_fraction_out = last_launch().sliced_fraction;
     return GSSS_OK;
 }
 

@@ -156,6 +156,7 @@ struct SlicePlan {
 struct LaunchInfo {
     int64_t grid;
     int32_t slice_steps;
+    double sliced_fraction;  // share of the chunks of chains that ran sliced (0 unsliced, 1 every chunk)
 };
 LaunchInfo &last_launch();  // gsss_capi.hip, thread local
 template <class Kern>
@@ -163,7 +164,7 @@ inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, in
 {
     SlicePlan p;
     p.grid = n_chunks;
-    last_launch() = LaunchInfo{n_chunks, 0};
+    last_launch() = LaunchInfo{n_chunks, 0, 0.0};
     if (!allowed) return p;
     const char *env = getenv("GSSS_SLICE_STEPS");  // (read per launch: tests switch it)
     const int env_val = env ? atoi(env) : 128;  // (measured at 10^5 chains x 1000 steps, d = 10 / 50 / 200: 64 -> 24.1 / 40.0 / 107.3 ms, 128 -> 23.8 / 39.7 / 106.1)
@@ -193,7 +194,7 @@ inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, in
     p.ws = static_cast<uint32_t *>(ws);
     p.grid = n_chunks * (1 + (rest > 0 ? (rest + env_steps - 1) / env_steps : 0));  // = SliceSched::take's n_items
     p.slice_steps = env_steps;
-    last_launch() = LaunchInfo{p.grid, p.slice_steps};
+    last_launch() = LaunchInfo{p.grid, p.slice_steps, 1.0};
     return p;
 }
 
@@ -201,7 +202,7 @@ inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, in
 // round of workgroups, and only when it is small: n_chunks = k resident + rem with rem <= 3/4 resident -- the first k resident
 // workgroups run the whole launch as ever (blockIdx < first), the rem chunks behind them are cut into slices that fill the
 // chip when the full rounds end.  (A slice of a lane kernel ends when its slowest lane does: ~10 % of lane tail at 128 steps,
-// paid on the partial round only.  At 10^6 chains: K = 10 mixture and compact Bingham 2.54 rounds -> sliced; headline 1.91 -> not.)
+// paid on the partial round only.  At 10^6 chains: K = 10 mixture and compact Bingham 2.54 rounds of 768 -> sliced; headline 1.53 rounds of 1280 -> sliced.)
 template <class Kern>
 inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock &rb, int64_t n_chunks, bool allowed, hipStream_t st,
                                     int32_t &first_out)
@@ -209,7 +210,7 @@ inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock 
     SlicePlan p;
     p.grid = n_chunks;
     first_out = 0;
-    last_launch() = LaunchInfo{n_chunks, 0};
+    last_launch() = LaunchInfo{n_chunks, 0, 0.0};
     if (!allowed) return p;
     const char *env = getenv("GSSS_SLICE_STEPS");
     const int env_val = env ? atoi(env) : 128;
@@ -242,7 +243,7 @@ inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock 
     p.grid = first + rem * n_slices;
     p.slice_steps = env_steps;
     first_out = (int32_t)first;
-    last_launch() = LaunchInfo{p.grid, p.slice_steps};
+    last_launch() = LaunchInfo{p.grid, p.slice_steps, (double)rem / (double)n_chunks};
     return p;
 }
 

@@ -245,8 +245,10 @@ int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);
  * the launch was SLICED (kernels whose chunks of chains do not fit the chip at once run one workgroup per (chunk, slice of steps)
  * and hand the chunk's state from slice to slice through HBM: (16 d + 32) / slice_steps more bytes per chain-step than an unsliced
  * launch; same results bit for bit; GSSS_SLICE_STEPS in the environment sets the length, 0 turns it off).  slice_steps 0:
- * unsliced; grid 0: a kernel family that never slices.  There is nothing in the reference this replaces. */
-int gsss_last_launch(int64_t *grid_out, int32_t *slice_steps_out);
+ * unsliced; grid 0: a kernel family that never slices.  sliced_fraction: the share of the chains that ran sliced (the lane
+ * kernels slice only a small last round of workgroups).  Any pointer may be NULL.  There is nothing in the reference this
+ * replaces. */
+int gsss_last_launch(int64_t *grid_out, int32_t *slice_steps_out, double *sliced_fraction_out);
 
 /* Number of rows of gsss_run_args.stats_dev for dimension d, K modes, L lags and the GSSS_STATS_* flags (< 0: bad argument). */
 int64_t gsss_stats_rows(int32_t d, int32_t n_modes, int32_t n_lags, int32_t flags);

@@ -829,7 +829,9 @@ def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, monkeypatc
         kept = [s.advance(m, thin=13) for m in (650, 520)]
         import ctypes as C
         grid, steps = C.c_int64(0), C.c_int32(0)
-        s._lib.gsss_last_launch(C.byref(grid), C.byref(steps))
+        frac = C.c_double(-1.0)
+        s._lib.gsss_last_launch(C.byref(grid), C.byref(steps), C.byref(frac))
+        assert (0.0 < frac.value < 0.75) if steps.value else frac.value == 0.0   # only a small last round is sliced
         out[label] = (s.state_device.clone(), torch.cat(kept), s._n_tries.clone(), s._n_reject.clone(), s._err.clone(), int(steps.value))
     assert out["whole"][5] == 0
     if out["sliced"][5] == 0:
