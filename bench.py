@@ -124,7 +124,11 @@ def issue_counters(workload, n, S, thin, mode, layout="chains"):
     shape = rec.get("launch", {})
     if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode"), shape.get("layout", "components")) != (n, S, thin, mode, layout):
         return {}
-    return dict(rec.get("issue", {}))
+    out = dict(rec.get("issue", {}))
+    if out:
+        out["valu_busy_meaning"] = ("4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): VALU-active wavefront cycles per SIMD "
+                                    "cycle; instructions of different wavefronts overlap in the pipeline, so five resident wavefronts can pass 1")
+    return out
 
 
 def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms, layout="chains"):

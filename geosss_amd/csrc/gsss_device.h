@@ -128,16 +128,28 @@ struct SliceSched {
         }
         return true;
     }
-    // after the chunk's stores: make them visible, then publish the slice
+    // after the chunk's stores: make them visible, then publish the slice.  kWrittenThrough: EVERY byte the next slice reads was
+    // stored by hand_over() below (write-through), so no release is needed -- the release writes back ALL dirty lines of this
+    // XCD's L2, among them the half-written lines of retained rows that lanes of the lane kernels fill at their own pace
+    // (measured on the README workload, a third of the chains sliced: 2 x FETCH + WRITE 690 MB per launch with the release).
+    template <bool kWrittenThrough = false>
     __device__ static __forceinline__ void publish(const RunBlock &a, const uint32_t *word)
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
         __syncthreads();
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!kWrittenThrough) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __hip_atomic_store(progress(a) + word[1], word[2] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    // a store of handed-over state that needs no release behind it: agent scope, i.e. written through this XCD's L2
+    template <class T>
+    __device__ static __forceinline__ void hand_over(T *p, T v)
+    {
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 

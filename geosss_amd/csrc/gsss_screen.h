@@ -962,15 +962,28 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         if constexpr (Chain::kCompact) tp.retail(reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));  // the margin
     };
 
+    // A slice's state, counters and flags go to the chunk's next slice: written through (SliceSched::hand_over), so that
+    // publishing them needs no write-back of the whole L2 (the statistics build hands its accumulators over with plain stores
+    // and keeps the release).
+#ifndef GSSS_HAND_OVER_PLAIN  // (A/B builds: 1 = plain stores and a release, as the group kernels do)
+#define GSSS_HAND_OVER_PLAIN 0
+#endif
+    constexpr bool kThrough = !STATS && !GSSS_HAND_OVER_PLAIN;
+    auto put_out = [&](auto *p, auto v) {
+        if (kThrough && sliced)
+            SliceSched::hand_over(p, v);
+        else
+            *p = v;
+    };
     auto flush = [&]() {
         const int32_t c = chain_id();
         if (c >= n) return;
 #pragma unroll
-        for (int j = 0; j < D; ++j) a.state[(size_t)j * n + c] = cur.x[j];
-        if (a.n_reject) a.n_reject[c] += (int64_t)cur.n_try - (cur.steps_done - s_begin);
-        if (a.n_tries) a.n_tries[c] += (int64_t)cur.n_try;
-        if (a.err && cur.err) a.err[c] |= cur.err;
-        if (sliced && cur.steps_done < n_steps) SliceSched::dead(a, kChunk)[c] = 1;  // stopped early: stays stopped
+        for (int j = 0; j < D; ++j) put_out(&a.state[(size_t)j * n + c], cur.x[j]);
+        if (a.n_reject) put_out(&a.n_reject[c], a.n_reject[c] + ((int64_t)cur.n_try - (cur.steps_done - s_begin)));
+        if (a.n_tries) put_out(&a.n_tries[c], a.n_tries[c] + (int64_t)cur.n_try);
+        if (a.err && cur.err) put_out(&a.err[c], a.err[c] | cur.err);
+        if (sliced && cur.steps_done < n_steps) put_out(&SliceSched::dead(a, kChunk)[c], (int32_t)1);  // stopped early: stays stopped
     };
 
     if (kPark) {  // the chain of slot 1 is initialised, set up and parked; then the chain of slot 0
@@ -1054,7 +1067,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         trade();
         flush();
     }
-    if (sliced) SliceSched::publish(a, sched_word);
+    if (sliced) SliceSched::publish<kThrough>(a, sched_word);
 }
 
 template <int D, class TP, bool REPLAY>
