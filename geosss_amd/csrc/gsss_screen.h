@@ -1062,6 +1062,10 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         }
     }
     if (stuck && cur.status != kDone) cur.err |= GSSS_CHAIN_MAX_TRIES | GSSS_CHAIN_COUNTER_SATURATED;
+    // every lane stores its chain of slot 0, then its chain of slot 1: a wavefront's stores are then whole 512-byte runs (lanes that
+    // ended on different slots wrote every line in two halves -- twice the bytes once the hand-over is written through: K = 10
+    // mixture 76 bytes per chain and slice where 40 are due)
+    if (kPark && slot == 1) trade();
     flush();
     if (kPark) {
         trade();

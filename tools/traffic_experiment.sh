@@ -4,7 +4,7 @@
 set -u
 W=$1; CH=$2; shift 2
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-ess --workload $W --chains $CH --no-configs"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-ess --workload $W --chains $CH --no-configs ${TX_EXTRA:-}"  # TX_EXTRA: more bench flags
 for S in "$@"; do
   export GSSS_SLICE_STEPS=$S
   OUT=gpurun_out/tx_${W}_$S
