@@ -864,3 +864,32 @@ def test_sliced_launch_long_hand_over_chain(gs, monkeypatch):
         for i in range(5):
             assert torch.equal(out["whole"][i], out[label][i]), (label, i)
     assert int((out["whole"][4] != 0).sum()) == 0
+
+
+def test_sliced_partial_round_long_hand_over_chain(gs, monkeypatch):
+    """The bench's headline launch -- 10^6 README chains x 1000 steps, the last partial round of workgroups cut into sixteen
+    64-step slices (eight of 128), each chunk's state written THROUGH from XCD to XCD (SliceSched::hand_over: no release, only
+    the consumer's acquire) -- against the unsliced launch: every state bit, every retained row, every counter."""
+    import torch
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    n = 1_000_000
+    x0 = gs.sample_sphere_device(2, n, seed=49).T
+    out, sliced = {}, {}
+    for label, env in (("whole", "0"), ("s64", "64"), ("s128", "128")):
+        monkeypatch.setenv("GSSS_SLICE_STEPS", env)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=9, mode="fast", placement="packed")
+        assert _packed_kernel(s).startswith("screened_kernel")
+        kept = s.advance(1000, thin=100)
+        s.advance(1000)
+        import ctypes as C
+        steps = C.c_int32(0)
+        s._lib.gsss_last_launch(None, C.byref(steps), None)
+        sliced[label] = int(steps.value)
+        out[label] = (s.state_device.clone(), kept.clone(), s._n_tries.clone(), s._n_reject.clone(), s._err.clone())
+    if sliced["s128"] == 0:
+        pytest.skip("this box holds another number of workgroups of this kernel: nothing was sliced")
+    for label in ("s64", "s128"):
+        for i in range(5):
+            assert torch.equal(out["whole"][i], out[label][i]), (label, i)
+    assert int((out["whole"][4] != 0).sum()) == 0

@@ -253,6 +253,34 @@ def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placem
     assert torch.equal(t._stats["acc"], s._stats["acc"])
 
 
+@pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1024), ("bingham_d10_vmax30", 512)])
+def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, monkeypatch):
+    """The statistics build of the lane kernels slices its last partial round like the plain build (plan_partial_round) and
+    hands the accumulators from slice to slice with plain stores behind an agent-scope release: the same bits as unsliced."""
+    import ctypes as C
+    import torch
+    from conftest import golden
+    from helpers import product_target
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    n_chains = (resident + 29) * 512 - 77
+    x0 = gs.sample_sphere_device(d - 1, n_chains, seed=15).T
+    out = {}
+    for label, env in (("whole", "0"), ("sliced", "128")):
+        monkeypatch.setenv("GSSS_SLICE_STEPS", env)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=12, mode="fast", placement="packed", step_offset=55).enable_stats(lags=8)
+        s.advance(700, thin=7, keep=False)
+        steps = C.c_int32(0)
+        s._lib.gsss_last_launch(None, C.byref(steps), None)
+        out[label] = (s._stats["acc"].clone(), s.state_device.clone(), s._n_tries.clone(), int(steps.value))
+    assert out["whole"][3] == 0
+    if out["sliced"][3] == 0:
+        pytest.skip("this box holds another number of workgroups of this kernel: nothing was sliced")
+    for i in range(3):
+        assert torch.equal(out["whole"][i], out["sliced"][i]), i
+
+
 def test_running_statistics_second_moment_limit(gs):
     """d (d + 1) / 2 second-moment rows per chain: accumulated up to d = 64, refused with a message beyond (20 100 rows at d = 200)."""
     from conftest import golden
