@@ -582,10 +582,13 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
     }
 
     const int draws = replay ? kDrawsReplay : (a->rng_state_dev ? kDrawsNumpy : kDrawsPhilox);
-    if (a->mode == GSSS_MODE_FAST && a->rng_state_dev && !(rb.spread && t->tb.d <= 16)) {
-        set_error("in fast mode the numpy stream is served by the one-wavefront-per-chain kernel only "
-                  "(spread placement, d <= 16); use GSSS_MODE_EXACT");
-        return GSSS_E_UNSUPPORTED;
+    if (a->mode == GSSS_MODE_FAST && a->rng_state_dev) {  // a generator per chain: the lane-per-chain shapes only
+        FastProbe pr;
+        if (fast_dispatch(t->tb, rb, false, &pr, nullptr) != GSSS_OK || !pr.lane) {
+            set_error("in fast mode the numpy stream is served by the lane-per-chain kernels only (gsss_variant_name: "
+                      "\"fast-lane\"); use GSSS_MODE_EXACT");
+            return GSSS_E_UNSUPPORTED;
+        }
     }
     if (a->mode == GSSS_MODE_FAST) {
         if (a->n_steps > 0x7FFFFFFFll || a->thin > 0x7FFFFFFFll || a->n_chains > 0x7FFFFFFFll - 1024 ||

@@ -405,9 +405,13 @@ __host__ __device__ constexpr size_t fast_lds_doubles()
                                 : 0);
 }
 
-template <int D, class TP, bool REPLAY, bool STATS = false>
+// NUMPY: the draws come from numpy's own PCG64 / ziggurat stream (rng_state, NumpyDraws) instead of the replay buffer, at
+// the replay path's consumption points -- the reference's own order, a uniform per try that is made and none for one that is
+// not.  A generator per chain: one chain per lane (nothing is parked), the ziggurat tables where the parked chains would be.
+template <int D, class TP, bool REPLAY, bool STATS = false, bool NUMPY = false>
 __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a)
 {
+    static_assert(!NUMPY || REPLAY, "numpy's stream is a sequential source: it is read where the replay buffer is");
     using V = LaneVec<D>;
     using Chain = FastChain<D, TP>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -416,6 +420,8 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     const fm::Tables tab = stage_tables(lds + TP::lds_doubles());
     // word w of this lane's parked chain lives at park[w * kBlock]: conflict-free across lanes
     unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles() + kTabLds) + threadIdx.x;
+    NumpyDraws<V> nd;
+    if constexpr (NUMPY) nd.stage(lds + TP::lds_doubles() + kTabLds);
     __syncthreads();
 
     const int32_t n = (int32_t)a.n_chains;
@@ -424,12 +430,13 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
     const int32_t thin = (int32_t)a.thin;
     const int32_t max_tries = a.max_tries < (1 << 26) ? a.max_tries : (1 << 26) - 1;  // t shares a word with the flags
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
-    constexpr bool kPark = fast_parks<D, TP>();
+    constexpr bool kPark = fast_parks<D, TP>() && !NUMPY;
+    constexpr int kPerBlock = kPark ? 2 * kBlock : kBlock;
     // packed: lane l of block b owns chains b*P + l and (parking targets) b*P + 256 + l.
     // spread (small ensembles): one chain per wavefront, owned by its lane 0; nothing is parked.
     const bool spread = a.spread != 0;
     const int32_t id0 = spread ? ((threadIdx.x % 64 == 0) ? (int32_t)blockIdx.x * (kBlock / 64) + (int32_t)threadIdx.x / 64 : n)
-                               : (int32_t)blockIdx.x * fast_chains_per_block<D, TP>() + (int32_t)threadIdx.x;
+                               : (int32_t)blockIdx.x * kPerBlock + (int32_t)threadIdx.x;
     const int32_t id1 = spread ? n : id0 + kBlock;
 
     Chain cur;
@@ -445,6 +452,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         return dr;
     };
     auto replay_take = [&]() -> double {
+        if constexpr (NUMPY) return nd.next_double();
         if (cur.cursor >= (int32_t)a.replay_stride) {
             cur.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
             return 0.5;
@@ -471,6 +479,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         cur.lvl = 0.0;
         cur.t = 0;
         cur.status = (valid && n_steps > 0) ? kPending : kDone;
+        if constexpr (NUMPY) nd.init(a, cc, D);
     };
 
     // everything a step needs before its first try (mcmc.py:387-392)
@@ -478,7 +487,10 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         double u_thr, u_th0;
         uint32_t w_phi = 0u;  // S^2, Philox stream: the angle word of the tangent direction
         if (REPLAY) {
-            if (cur.cursor + D <= (int32_t)a.replay_stride) {
+            if constexpr (NUMPY) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) cur.u[j] = nd.standard_normal();
+            } else if (cur.cursor + D <= (int32_t)a.replay_stride) {
 #pragma unroll
                 for (int j = 0; j < D; ++j)
                     cur.u[j] = a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor + j];
@@ -641,6 +653,7 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
         if (a.n_reject) a.n_reject[c] += (int64_t)cur.n_try - cur.steps_done;
         if (a.n_tries) a.n_tries[c] += (int64_t)cur.n_try;
         if (a.err && cur.err) a.err[c] |= cur.err;
+        if constexpr (NUMPY) nd.finish(a, c, true);
     };
 
     // chain of slot 1 is initialised, set up and parked; then the chain of slot 0
@@ -729,6 +742,30 @@ int do_fast_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     return GSSS_OK;
 }
 
+// numpy's stream, one lane per chain (fast_kernel<..., NUMPY>)
+template <int D, class TP>
+int do_fast_numpy(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
+{
+    const size_t lds = (TP::lds_doubles() + kTabLds + NumpyDraws<LaneVec<D>>::kLdsDoubles) * sizeof(double);
+    auto kern = rb.stats != nullptr ? fast_kernel<D, TP, true, true, true> : fast_kernel<D, TP, true, false, true>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GSSS_E_HIP;
+        }
+    }
+    const int per_block = rb.spread ? kBlock / 64 : kBlock;
+    const int64_t grid = (rb.n_chains + per_block - 1) / per_block;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("fast kernel launch failed: %s", hipGetErrorString(e));
+        return GSSS_E_HIP;
+    }
+    return GSSS_OK;
+}
+
 template <int D, class TP>
 int do_wave(const TargetBlock &tb, const RunBlock &rb, hipStream_t st);
 
@@ -739,10 +776,7 @@ int do_fast(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t 
     if constexpr (D <= 16) {
         if (rb.spread) return do_wave<D, TP>(tb, rb, st);  // small ensemble: one wavefront per chain
     }
-    if (rb.rng_state != nullptr) {  // only the wave kernel reads numpy's stream
-        set_error("in fast mode the numpy stream needs spread placement and d <= 16; use GSSS_MODE_EXACT");
-        return GSSS_E_UNSUPPORTED;
-    }
+    if (rb.rng_state != nullptr) return do_fast_numpy<D, TP>(tb, rb, st);  // a generator per chain: one lane per chain
     return do_fast_run<D, TP, false>(tb, rb, st);
 }
 

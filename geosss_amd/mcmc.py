@@ -21,7 +21,9 @@ resident in HBM between calls.  Two random streams:
       like the reference (`np.random.default_rng(seed)`, mcmc.py:45) consumes exactly the numbers
       the reference consumes, so `Sampler(pdf, x0, seed).sample(n, burnin)` reproduces geosss's
       output from the seed alone (to rounding, ~1e-14).  For one chain `sampler.rng` is kept in
-      step with the device stream, as the reference's attribute would be.
+      step with the device stream, as the reference's attribute would be.  Many chains: one generator per
+      chain (a list of seeds, or SeedSequence(seed).spawn(n_chains)); fast mode serves the stream for the
+      lane-per-chain shapes (one lane per chain in large ensembles), the exact kernels for every shape.
 """
 import copy
 import ctypes as C
@@ -133,16 +135,15 @@ class RejectionSphericalSliceSampler:
         self._target_dev = distribution._device_target(self.device)
         self._set_state(initial_state)
         if rng == "numpy":
-            # sequential per chain: fast mode serves it with the one-wavefront-per-chain kernel only
-            wave_ok = (self._placement != 1 and self.n_chains <= 2048 and distribution.d <= 16 and not variant and
-                       self._lib.gsss_variant_name(self._target_dev.handle, _lib.MODE_FAST, 0) == b"fast-lane")
-            if mode == "fast" and not wave_ok:
-                raise ValueError("rng='numpy' in fast mode needs a small ensemble (<= 2048 chains, spread placement) "
-                                 "of a shape the fast kernels are built for; use mode='exact' or 'auto'")
+            # a generator per chain, sequential: fast mode serves it where a chain is one lane's (or, small ensembles, one
+            # wavefront's) -- the lane-per-chain shapes; the cooperative shapes run the exact kernels
+            lane_ok = not variant and self._lib.gsss_variant_name(self._target_dev.handle, _lib.MODE_FAST, 0) == b"fast-lane"
+            if mode == "fast" and not lane_ok:
+                raise ValueError("rng='numpy' in fast mode needs a shape the lane-per-chain fast kernels are built for "
+                                 "(vMF mixtures and Bingham targets up to d = 10, the listed curve dimensions); "
+                                 "use mode='exact' or 'auto'")
             if mode == "auto":
-                mode = self.mode = "fast" if wave_ok else "exact"
-            if mode == "fast":
-                self._placement = 2
+                mode = self.mode = "fast" if lane_ok else "exact"
         if mode == "auto":  # the throughput kernels where they are built for this shape, else the generic ones
             fast_ok = self._lib.gsss_mode_supported(self._target_dev.handle, _lib.MODE_FAST) and not variant
             self.mode = "fast" if fast_ok else "exact"

@@ -156,7 +156,8 @@ typedef struct gsss_run_args {
     uint64_t *rng_state_dev;   /* [n_chains][4] or NULL.  Non-NULL selects NUMPY'S OWN STREAM instead of Philox: per chain the
                                   PCG64 words (state_hi, state_lo, inc_hi, inc_lo) of np.random.default_rng(seed).bit_generator,
                                   read at entry and written back at exit, so a chain consumes exactly the numbers the reference's
-                                  sampler.rng would (mcmc.py:45, 387-395).  GSSS_MODE_EXACT, or GSSS_MODE_FAST with spread placement (d <= 16);
+                                  sampler.rng would (mcmc.py:45, 387-395).  GSSS_MODE_EXACT, or GSSS_MODE_FAST for the lane-per-chain shapes
+                                  (gsss_variant_name "fast-lane": one wavefront per chain when spread, one lane per chain when packed);
                                   `seed` and the offsets are then unused */
     int64_t samples_chain_rows; /* 0: samples_dev is [n_steps/thin][d][n_chains] (component-major, like state_dev).
                                    R > 0: samples_dev points into a [n_chains][R][d] array -- the reference's (chains, draws,

@@ -379,15 +379,16 @@ def test_readme_call_from_seed(gs):
 
 
 @pytest.mark.parametrize("name", trajectory_names("shrink") + trajectory_names("reject"))
-@pytest.mark.parametrize("mode", ["exact", "auto"])
+@pytest.mark.parametrize("mode", ["exact", "auto", "packed"])
 def test_reference_chain_from_seed(gs, name, mode):
     """Every golden reference chain reproduced on the GPU from (pdf, x0, seed) alone, by the exact kernels
-    and (mode auto: where built) by the speculative one-wavefront-per-chain kernel."""
+    and (mode auto: where built) by the speculative one-wavefront-per-chain kernel and (packed) by the lane-per-chain
+    kernel that serves numpy's stream to large ensembles (fast_kernel<..., NUMPY>)."""
     z = golden(name + ".npz")
     pdf = product_target(z)
     cls = gs.RejectionSphericalSliceSampler if str(z["sampler"]) == "reject" else gs.ShrinkageSphericalSliceSampler
-    s = cls(pdf, z["x0"], int(z["seed"]), rng="numpy", mode=mode)
-    if mode == "auto" and s.mode == "exact":
+    s = cls(pdf, z["x0"], int(z["seed"]), rng="numpy", **({"mode": "auto", "placement": "packed"} if mode == "packed" else {"mode": mode}))
+    if mode != "exact" and s.mode == "exact":
         pytest.skip("no fast kernel for this shape: covered by the exact run")
     n = len(z["states"]) - 1
     out = s.sample(n + 1)
@@ -418,8 +419,39 @@ def test_numpy_stream_many_chains(gs, oracle):
     got = s.advance(15, thin=1).permute(2, 0, 1).cpu().numpy()
     assert np.max(np.abs(got - want["samples"])) < TOL
     assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
-    with pytest.raises(ValueError):  # d = 50: no one-wavefront kernel, fast mode cannot serve numpy's stream
+    with pytest.raises(ValueError):  # d = 50: a cooperative shape, fast mode cannot serve numpy's stream
         gs.ShrinkageSphericalSliceSampler(pdf, x0, 1, rng="numpy", mode="fast")
+
+
+@pytest.mark.parametrize("name,n_chains", [("vmfmix_readme", 2500), ("vmfmix_d10_k5_kappa100", 700), ("bingham_d10_vmax30", 900),
+                                           ("curve_d10_kappa800", 600), ("curve_d24_kappa800", 300)])
+@pytest.mark.parametrize("sampler", ["shrink", "reject"])
+def test_numpy_stream_lane_kernel(gs, oracle, name, n_chains, sampler):
+    """numpy's stream for LARGE ensembles of the lane-per-chain shapes: one lane per chain, each with its own PCG64 / ziggurat
+    generator (fast_kernel<..., NUMPY>), against the oracle's numpy stream seeded the same way -- states at 1e-10, tries exact,
+    and every generator left where the exact kernels leave it (the same number of draws consumed, bit for bit)."""
+    z = golden(f"traj_{name}.npz")
+    pdf, tgt = product_target(z), oracle.Target.from_fixture(z)
+    d = len(z["x0"])
+    root = np.random.SeedSequence(2024)
+    x0 = oracle.sample_sphere(3, n_chains, d)   # (seed, chains, dimension)
+    n_steps = 25 if sampler == "shrink" else 6
+    kind = oracle.REJECT if sampler == "reject" else oracle.SHRINK
+    want = oracle.run(tgt, x0, n_steps, numpy_seed=list(root.spawn(n_chains)), sampler=kind)
+    cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    s = cls(pdf, x0, np.random.SeedSequence(2024), rng="numpy", mode="fast", placement="packed")
+    got = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
+    assert np.max(np.abs(got - want["samples"])) < TOL
+    assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    e = cls(pdf, x0, np.random.SeedSequence(2024), rng="numpy", mode="exact")
+    e.advance(n_steps)
+    import torch
+    assert torch.equal(s._rng_state, e._rng_state)
+    assert np.array_equal(s._rng_state.cpu().numpy().view(np.uint64), np.asarray(want["pcg"]).reshape(n_chains, 4))
+    # and a second launch continues each generator
+    more = s.advance(5, thin=1).permute(2, 0, 1).cpu().numpy()
+    want2 = oracle.run(tgt, x0, n_steps + 5, numpy_seed=list(np.random.SeedSequence(2024).spawn(n_chains)), sampler=kind)
+    assert np.max(np.abs(more - want2["samples"][:, n_steps:])) < TOL
 
 
 def test_edge_shapes(gs):
