@@ -522,10 +522,19 @@ def test_c_abi_argument_errors(gs):
                      (dict(chain_offset=2**48), -1),
                      (dict(replay_dev=st.data_ptr(), replay_stride=0), -1),
                      (dict(replay_dev=st.data_ptr(), replay_stride=4, rng_state_dev=words.data_ptr()), -1),
-                     (dict(rng_state_dev=words.data_ptr(), mode=1, placement=1), -2),   # numpy stream + packed fast kernel
                      (dict(placement=3), -1), (dict(samples_chain_rows=-1), -1)):
         rc, msg = run(**kw)
         assert rc == code and msg, (kw, rc, msg)
+    assert run(rng_state_dev=words.data_ptr(), mode=1, placement=1)[0] == 0   # numpy's stream, one lane per chain
+    # numpy's stream in fast mode on a cooperative shape (a chain is several lanes'): unsupported
+    zc = golden("traj_curve_d50_kappa800.npz")
+    pdf_c = product_target(zc)                       # (kept alive: the handle is its)
+    hc = pdf_c._device_target(0).handle
+    stc = torch.zeros(50, 8, dtype=torch.float64, device="cuda")
+    stc[0] = 1.0
+    a = _lib.RunArgs(state_dev=stc.data_ptr(), n_chains=8, n_steps=1, thin=1, seed=1, sampler=0, mode=1, max_tries=10,
+                     rng_state_dev=words.data_ptr())
+    assert lib.gsss_run(hc, C.byref(a), None) == -2 and b"lane-per-chain" in lib.gsss_last_error()
     assert lib.gsss_run(None, None, None) == -1
     assert run(n_chains=0)[0] == 0
     # target descriptions
