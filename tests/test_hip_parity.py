@@ -852,7 +852,8 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
 
 @pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1280), ("vmfmix_k10_kappa500", 768), ("bingham_d10_vmax30", 768),
                                            ("vmfmix_d10_k5_kappa100", 512)])
-def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, monkeypatch):
+@pytest.mark.parametrize("sampler", ["shrink", "reject"])
+def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, sampler, monkeypatch):
     """The lane kernels (two chains per lane) cut only a SMALL last round of workgroups into step slices
     (plan_partial_round, gsss_device.h): an ensemble of k x resident + a few workgroups gives the same bits -- states,
     retained rows, tries, rejections, error flags -- sliced or not, and a chain that stops in one slice stays stopped."""
@@ -865,9 +866,10 @@ def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, monkeypatc
     out = {}
     for label, env in (("whole", "0"), ("sliced", "128")):
         monkeypatch.setenv("GSSS_SLICE_STEPS", env)
-        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=6, mode="fast", placement="packed", step_offset=91, max_tries=24)
+        cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+        s = cls(pdf, x0, seed=6, mode="fast", placement="packed", step_offset=91, max_tries=24 if sampler == "shrink" else 1 << 20)
         assert _packed_kernel(s).startswith("screened_kernel")
-        kept = [s.advance(m, thin=13) for m in (650, 520)]
+        kept = [s.advance(m, thin=13) for m in ((650, 520) if sampler == "shrink" else (300,))]
         import ctypes as C
         grid, steps = C.c_int64(0), C.c_int32(0)
         frac = C.c_double(-1.0)
@@ -882,7 +884,10 @@ def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, monkeypatc
     for i in (0, 2, 3, 4):
         assert torch.equal(out["whole"][i], out["sliced"][i]), i
     assert torch.equal(out["whole"][1][:, :, ok], out["sliced"][1][:, :, ok])
-    assert 0 < int((err != 0).sum()) < n_chains
+    if sampler == "shrink":
+        assert 0 < int((err != 0).sum()) < n_chains
+    else:
+        assert int((err != 0).sum()) == 0
 
 
 def test_sliced_launch_long_hand_over_chain(gs, monkeypatch):
