@@ -47,12 +47,22 @@ __host__ __device__ constexpr int curvespec_scratch_doubles()
 {
     return 2 + 4 * L + 2 * NK;  // U_threshold, U_theta0 | a ring of 4 L try uniforms | the step's double-precision coefficients
 }
-template <int L, int Q, int NK>
+// The tangent u rests in LDS while the tries run where the registers would not hold it beside the try loop's: the 17-knot
+// builds with more than four components per lane.  (Round 3: the 10-knot builds kept parking it at two wavefronts per SIMD, where
+// 256 registers are to be had -- without, <4, 4, 10> takes 254 and <16, 4, 10> 246, nothing spilled: d = 50 35.3 -> 34.9 ms,
+// d = 200 99.4 -> 97.4 ms per 10^8 chain-steps.)
+// (HEAVY: the replay and statistics builds carry more state and keep parking it.)
+template <int Q, int NK, bool HEAVY>
+__host__ __device__ constexpr bool curvespec_parks_u()
+{
+    return Q >= 2 && (NK > 10 || HEAVY);
+}
+template <int L, int Q, int NK, bool HEAVY>
 __host__ __device__ constexpr size_t curvespec_lds_doubles()
 {
     return (size_t)NK * (4 * Q * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
            (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2 +
-           (Q >= 2 ? (size_t)4 * Q * kBlock : 0);  // Q >= 2: the tangent u rests in LDS while the tries run
+           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)4 * Q * kBlock : 0);
 }
 
 // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397), FastCurve::level
@@ -164,7 +174,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     const fm::Tables tab = stage_tables(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L));
     // Q >= 2 (d > 64): u is only needed again when the chain moves; its 8 Q registers are lent to the try loop meanwhile
     // (slots 2 p, 2 p + 1 of thread t at [p][t][2]: 16-byte accesses, conflict-free)
-    constexpr bool kParkU = Q >= 2;
+    constexpr bool kParkU = curvespec_parks_u<Q, NK, REPLAY || STATS>();
     double2 *upark = reinterpret_cast<double2 *>(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2) + threadIdx.x;
     Scalar sc;
     sc.knots = lds;
@@ -565,7 +575,7 @@ int do_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStre
         set_error("curvespec kernel <%d, %d, %d> cannot hold d=%d, %d knots", L, Q, NK, tb.d, tb.k);
         return GSSS_E_UNSUPPORTED;
     }
-    const size_t lds = curvespec_lds_doubles<L, Q, NK>() * sizeof(double);
+    const size_t lds = (replay || rb.stats != nullptr ? curvespec_lds_doubles<L, Q, NK, true>() : curvespec_lds_doubles<L, Q, NK, false>()) * sizeof(double);
     auto kern = replay ? curvespec_kernel<L, Q, NK, true> : curvespec_kernel<L, Q, NK, false>;
     if (rb.stats != nullptr) {  // running statistics: a build of its own (the plain kernel carries none of it)
         if (replay) {
