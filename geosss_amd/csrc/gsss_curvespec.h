@@ -1,4 +1,4 @@
-// gsss_curvespec.h -- curve-vMF targets at 9 <= d <= 256: L lanes per chain, L speculative tries per batch,
+// gsss_curvespec.h -- curve-vMF targets at 4 <= d <= 256 (launch_fast_curve says from where): L lanes per chain, L speculative tries per batch,
 // every try screened in single precision.
 //
 // The lane-per-chain kernels hold x, u and 2 NK coefficients of a chain in one lane: from d = 9 on that is more than

@@ -11,8 +11,11 @@ int launch_fast_curve(const TargetBlock &tb, const RunBlock &rb, bool replay, Fa
 {
     // (knot counts: what the all-double / one-wavefront kernels below cover too, so that a shape is either served in every
     // placement and variant or in none)
+    // d >= 4: on S^2 the Philox stream draws the tangent as one angle, which only the lane kernels do.  (Round 3: from d = 4,
+    // not 9 -- 10^5 chains, 10^9 chain-steps/s: d = 6 2.97 (screened lane kernel) -> 4.74, d = 4, 5, 7, 8 1.05 (sixteen-lane
+    // cooperative kernel) -> 4.6 .. 4.8.)
     const bool spec = rb.screen && !rb.spread && rb.rng_state == nullptr && tb.k >= 2 &&
-                      tb.k <= (tb.d > 64 ? 17 : 16) && tb.d >= 9 && tb.d <= 256;
+                      tb.k <= (tb.d > 64 ? 17 : 16) && tb.d >= 4 && tb.d <= 256;
     // lane-per-chain kernels: the listed dimensions, any curve of 2 .. 10 knots (built for 10; FastCurve pads)
 #define GSSS_CASE(D)                                                \
     if (tb.d == D && tb.k >= 2 && tb.k <= 10) {                     \

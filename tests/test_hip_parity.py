@@ -256,7 +256,7 @@ def test_error_reporting(gs):
 
 @pytest.mark.parametrize("d", [10, 50, 200])
 def test_group_speculative_curve_kernel_error_paths(gs, oracle, d):
-    """The group-speculative curve kernel (packed fast mode, d >= 9): max_tries, a NaN state and a replay stream that runs
+    """The group-speculative curve kernel (packed fast mode, d >= 4): max_tries, a NaN state and a replay stream that runs
     out flag the chain concerned -- and only it --, counters stay consistent, nothing spins."""
     z = golden(f"traj_curve_d{d}_kappa800.npz")
     pdf = product_target(z)
@@ -316,7 +316,7 @@ SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16
          # d = 64 | 65, 128 | 129, 192 | 193, 256; knot builds 10 | 17; every lane holding normals: d = 13 .. 16, 61 .. 64)
          ("curve", 9, 2), ("curve", 13, 10), ("curve", 16, 10), ("curve", 17, 3), ("curve", 12, 16), ("curve", 61, 10),
          ("curve", 64, 11), ("curve", 65, 10), ("curve", 128, 5), ("curve", 129, 10), ("curve", 192, 17), ("curve", 193, 10),
-         ("curve", 256, 10),
+         ("curve", 256, 10), ("curve", 4, 10), ("curve", 5, 3), ("curve", 8, 10),
          # cooperative mixture kernels: slots per lane 4 | 8 | 16 at d = 64 | 65, 128 | 129; up to 256
          ("vmf", 64, 3), ("vmf", 65, 5), ("vmf", 128, 3), ("vmf", 129, 2), ("vmf", 256, 16)]
 
@@ -345,6 +345,8 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
         s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement=placement)
         if (kind == "vmf" and k <= 16 and d <= 256) or (kind == "curve" and d <= 256):
             assert s.mode == "fast"
+        if kind == "curve" and 4 <= d <= 256 and placement == "packed":      # the group-speculative kernel from d = 4 on
+            assert _packed_kernel(s).startswith("curvespec_kernel")
         kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
         assert np.all(s.errors == 0)
         assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
@@ -763,7 +765,7 @@ def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
     assert torch.equal(out[True][1], out[False][1])
     assert torch.equal(out[True][2], out[False][2])
     if spec:
-        # The group-speculative curve kernel (d >= 9) arranges its sums differently from the all-double lane kernel: same
+        # The group-speculative curve kernel (d >= 4) arranges its sums differently from the all-double lane kernel: same
         # decisions (integer outputs above), states to rounding -- and bit for bit against ITSELF with the screen's verdicts
         # ignored (every try decided in double precision by the same arithmetic).
         assert float((out[True][0] - out[False][0]).abs().max().item()) < 1e-11
