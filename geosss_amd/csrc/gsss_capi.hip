@@ -553,7 +553,11 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("placement must be 0 (auto), 1 (packed) or 2 (spread)");
         return GSSS_E_INVALID;
     }
-    rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= 2048) ? 1 : 0;
+    // The library's choice: one wavefront per chain while that beats the packed throughput kernels (tools/bench_placement.py,
+    // fast mode, chain-steps/s packed | spread: README mixture 4096 chains 5.7e8 | 9.4e8, 8192 1.13e9 | 1.01e9; Bingham d = 10
+    // 4.6e8 | 8.4e8, 9.3e8 | 8.7e8; curve d = 10 (group kernel) 1024 chains 1.3e8 | 2.0e8, 2048 2.6e8 | 2.0e8).
+    const int64_t spread_max = a->mode != GSSS_MODE_FAST ? 2048 : (t->tb.kind == GSSS_CURVE_VMF ? 1536 : 4096);
+    rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= spread_max) ? 1 : 0;
     rb.screen = (a->mode == GSSS_MODE_FAST && a->variant == GSSS_VARIANT_FAST_DOUBLE) ? 0 : (a->variant == GSSS_VARIANT_FAST_VERIFY ? 2 : 1);
     rb.stats = a->stats_dev;
     rb.stats_dirs = a->stats_dirs_dev;
