@@ -554,9 +554,10 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         return GSSS_E_INVALID;
     }
     // The library's choice: one wavefront per chain while that beats the packed throughput kernels (tools/bench_placement.py,
-    // fast mode, chain-steps/s packed | spread: README mixture 4096 chains 5.7e8 | 9.4e8, 8192 1.13e9 | 1.01e9; Bingham d = 10
-    // 4.6e8 | 8.4e8, 9.3e8 | 8.7e8; curve d = 10 (group kernel) 1024 chains 1.3e8 | 2.0e8, 2048 2.6e8 | 2.0e8).
-    const int64_t spread_max = a->mode != GSSS_MODE_FAST ? 2048 : (t->tb.kind == GSSS_CURVE_VMF ? 1536 : 4096);
+    // fast mode, chain-steps/s packed (one chain per lane at these sizes) | spread: README mixture 3072 chains 8.3e8 | 9.0e8,
+    // 4096 1.11e9 | 0.95e9; K = 10 mixture 2048 3.7e8 | 4.4e8, 3072 5.5e8 | 4.5e8; Bingham d = 10 3072 6.9e8 | 8.0e8, 4096
+    // 9.2e8 | 8.4e8; curve d = 10 (group kernel) 1024 chains 1.3e8 | 2.0e8, 2048 2.6e8 | 2.0e8).
+    const int64_t spread_max = a->mode != GSSS_MODE_FAST ? 2048 : (t->tb.kind == GSSS_CURVE_VMF ? 1536 : 3072);
     rb.spread = a->placement == 2 || (a->placement == 0 && a->n_chains <= spread_max) ? 1 : 0;
     rb.screen = (a->mode == GSSS_MODE_FAST && a->variant == GSSS_VARIANT_FAST_DOUBLE) ? 0 : (a->variant == GSSS_VARIANT_FAST_VERIFY ? 2 : 1);
     rb.stats = a->stats_dev;

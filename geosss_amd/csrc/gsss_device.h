@@ -45,6 +45,8 @@ struct RunBlock {
     int32_t sampler, max_tries;
     int64_t keep_rows;  // > 0: samples are written chain-major [chain][keep_rows][d]; 0: [row][d][chain]
     int32_t spread;     // lane layouts: one chain per WAVEFRONT (small ensembles: no divergence between chains)
+    int32_t one_per_lane;  // the lane kernels that park a second chain per lane: leave it out (mid-size ensembles: twice the
+                           // workgroups while they all fit the chip at once; set by do_screened_run)
     int32_t screen;     // fast mode: tries are screened in single precision where the target's kernel is built for it
                         // (2: verification -- the screen's verdicts are ignored by the kernels that can, see gsss.h)
     double *stats;             // NULL or [gsss_stats_rows][n_chains] running statistics of the retained series

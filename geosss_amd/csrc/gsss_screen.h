@@ -699,8 +699,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
     constexpr bool kPark = screen_parks<D, TP>();
     constexpr int kPerBlock = kPark ? 2 * kBlock : kBlock;
-    const int32_t id0 = (int32_t)chunk * kPerBlock + (int32_t)threadIdx.x;
-    const int32_t id1 = id0 + kBlock;
+    // (one_per_lane: kBlock chains per workgroup, the lane's second slot stays empty -- a chain id past the ensemble)
+    const int32_t id0 = (int32_t)chunk * (a.one_per_lane ? kBlock : kPerBlock) + (int32_t)threadIdx.x;
+    const int32_t id1 = a.one_per_lane ? n : id0 + kBlock;
 
     Chain cur;
     int32_t slot = 0;
@@ -1090,12 +1091,28 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
             return GSSS_E_HIP;
         }
     }
-    const int per_block = screen_parks<D, TP>() ? 2 * kBlock : kBlock;
+    int per_block = screen_parks<D, TP>() ? 2 * kBlock : kBlock;
+    // Mid-size ensembles: while one chain per lane still fits the chip in ONE round of workgroups, the second chain of a lane is
+    // worth less than a second wavefront somewhere else (tools/bench_placement.py).
+    bool one_per_lane = false;
+#ifndef GSSS_ONE_PER_LANE  // (A/B builds: 0 = never)
+#define GSSS_ONE_PER_LANE 1
+#endif
+    if (GSSS_ONE_PER_LANE && screen_parks<D, TP>() && !REPLAY) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) == hipSuccess && per_cu >= 1 &&
+            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 1)
+            one_per_lane = (rb.n_chains + kBlock - 1) / kBlock <= (int64_t)per_cu * cus;
+        else
+            (void)hipGetLastError();
+    }
+    if (one_per_lane) per_block = kBlock;
     const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
     // a small last round of workgroups is cut into step slices (plan_partial_round, gsss_device.h)
     int32_t first = 0;
-    const SlicePlan plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>(), st, first);
+    const SlicePlan plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>() && !one_per_lane, st, first);
     RunBlock rbl = rb;
+    rbl.one_per_lane = one_per_lane ? 1 : 0;
     rbl.sched = plan.ws;
     rbl.slice_steps = plan.slice_steps;
     rbl.sched_first = first;

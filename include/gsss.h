@@ -163,7 +163,7 @@ typedef struct gsss_run_args {
                                    R > 0: samples_dev points into a [n_chains][R][d] array -- the reference's (chains, draws,
                                    dims) order -- and this call writes rows 0 .. n_steps/thin-1 of every chain's run of R rows
                                    (offset the pointer by row0*d doubles to continue a run across calls) */
-    int32_t placement;         /* lane-per-chain kernels: 0 = library's choice (spread for small ensembles: <= 4096 chains in fast mode, 1536 for curve targets, 2048 in exact mode), 1 = packed
+    int32_t placement;         /* lane-per-chain kernels: 0 = library's choice (spread for small ensembles: <= 3072 chains in fast mode, 1536 for curve targets, 2048 in exact mode), 1 = packed
                                   (64 chains per wavefront: throughput), 2 = spread (one chain per wavefront: chains of a
                                   small ensemble do not wait for each other's shrink loops; same numbers either way) */
     int32_t stats_lags;        /* L >= 0: lags of the running autocovariance sums (see stats_dev) */

@@ -941,3 +941,29 @@ def test_sliced_partial_round_long_hand_over_chain(gs, monkeypatch):
         for i in range(5):
             assert torch.equal(out["whole"][i], out[label][i]), (label, i)
     assert int((out["whole"][4] != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["vmfmix_readme", "vmfmix_k10_kappa500", "bingham_d10_vmax30"])
+def test_one_chain_per_lane_equals_two(gs, name):
+    """Mid-size ensembles run the lane kernels with ONE chain per lane (twice the workgroups while they fit the chip in one round,
+    RunBlock::one_per_lane); large ones park a second chain per lane.  Chains are keyed by their id: the first 40 000 chains
+    of a 700 000-chain ensemble (two per lane) equal the same 40 000 run on their own (one per lane), bit for bit."""
+    import torch
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    n_big, n_small = 700_000, 40_000
+    x0 = gs.sample_sphere_device(d - 1, n_big, seed=53).T
+    out = {}
+    for label, n in (("big", n_big), ("small", n_small)):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0[:n].contiguous(), seed=10, mode="fast", placement="packed")
+        assert _packed_kernel(s).startswith("screened_kernel")
+        kept = s.advance(120, thin=40)
+        import ctypes as C
+        grid = C.c_int64(0)
+        s._lib.gsss_last_launch(C.byref(grid), None, None)
+        out[label] = (s.state_device[:, :n_small].clone(), kept[:, :, :n_small].clone(), s._n_tries[:n_small].clone(), int(grid.value))
+    assert out["small"][3] == (n_small + 255) // 256          # one chain per lane: 256-chain workgroups
+    assert out["big"][3] >= (n_big + 511) // 512 and out["big"][3] < (n_big + 255) // 256
+    for i in range(3):
+        assert torch.equal(out["big"][i], out["small"][i]), i
