@@ -278,17 +278,19 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def pick_layout(layout, kernel_name, d):
+def pick_layout(layout, kernel_name, d, thin=100):
     """--layout auto: the layout that moves the fewest bytes for the kernel family (measured, tools/layout_experiment.sh; both are
     what the C ABI offers, gsss_run_args.samples_chain_rows).  The group kernels step a wavefront's chains together, so a kept
     row leaves as whole 512-byte runs per component: component-major.  The lane kernels keep a chain's row when ITS step count
     says so: 8-byte stores into eight chains' shared 64-byte lines at different times (WRITE_SIZE 2.6 GB for the 0.8 GB of
     kept rows of Bingham d = 10); chain-major, a chain's 8 d bytes are contiguous and leave together (1.2 GB) -- unless a row is
-    smaller than a line (d = 3: 24 bytes; chain-major 0.55 GB against 0.29 GB)."""
+    smaller than a line AND rows are far apart in time (d = 3, thin = 100: 24 bytes; chain-major 0.55 GB against 0.29 GB).  When
+    nearly every state is kept (thin <= 16) a chain's consecutive rows fill its lines within a few steps: chain-major again
+    (d = 3, thin = 1, 10^6 chains x 200 steps: 6.6 against 9.1 ms per launch, 3.0e10 against 2.2e10 chain-steps/s)."""
     if layout != "auto":
         return layout
     lane = kernel_name.startswith(("screened_kernel", "fast_kernel"))
-    return "chains" if lane and 8 * d >= 64 else "components"
+    return "chains" if lane and (8 * d >= 64 or thin <= 16) else "components"
 
 
 def kept_buffer(torch, layout, n, S, thin, d):
@@ -308,7 +310,7 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
     thin = 100
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
-    layout = pick_layout(layout, lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(), d)
+    layout = pick_layout(layout, lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(), d, thin)
     kept, kw = kept_buffer(torch, layout, n, S, thin, d)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -421,7 +423,7 @@ def main(argv=None):
     S = args.inner
     thin = min(args.thin, S) if args.thin > 0 else S
     layout = pick_layout(args.layout, gs._lib.load().gsss_kernel_name(
-        sampler._target_dev.handle, gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT, args.variant, 1).decode(), d)
+        sampler._target_dev.handle, gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT, args.variant, 1).decode(), d, thin)
     kept, kw = kept_buffer(torch, layout, n, S, thin, d)
     counts = [n] * world                             # chains per rank are fixed: no size exchange per gather
 
