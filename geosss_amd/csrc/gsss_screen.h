@@ -1095,10 +1095,8 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     // Mid-size ensembles: while one chain per lane still fits the chip in ONE round of workgroups, the second chain of a lane is
     // worth less than a second wavefront somewhere else (tools/bench_placement.py).
     bool one_per_lane = false;
-#ifndef GSSS_ONE_PER_LANE  // (A/B builds: 0 = never)
-#define GSSS_ONE_PER_LANE 1
-#endif
-    if (GSSS_ONE_PER_LANE && screen_parks<D, TP>() && !REPLAY) {
+    const char *env_one = getenv("GSSS_ONE_PER_LANE");  // "0": always two chains per lane (tests run both packings)
+    if (!(env_one && env_one[0] == '0') && screen_parks<D, TP>() && !REPLAY) {
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) == hipSuccess && per_cu >= 1 &&
             hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 1)

@@ -322,9 +322,10 @@ SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16
 
 
 @pytest.mark.parametrize("kind,d,k", SYNTH)
-def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
+def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k, monkeypatch):
     """Shapes without a reference fixture (every kernel family and layout boundary): device chains
-    (default mode) equal the oracle's on the same Philox stream; log_prob agrees as well."""
+    (default mode) equal the oracle's on the same Philox stream; log_prob agrees as well.  (The lane kernels pack an ensemble of
+    this size one chain per lane; "packed2" forces the large ensembles' two chains per lane, GSSS_ONE_PER_LANE=0.)"""
     rng = np.random.default_rng(1000 * d + k)
     if kind == "vmf":
         mu = 40.0 * oracle.sample_sphere(5, k, d)
@@ -341,7 +342,12 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k):
     n_chains, n_steps = (70, 12) if d > 64 else (333, 25)
     x0 = oracle.sample_sphere(3, n_chains, d)
     want = oracle.run(tgt, x0, n_steps, seed=77, n_threads=8)
-    for placement in ("auto", "packed"):  # small ensemble: one wavefront per chain; packed: the throughput kernels
+    for placement in ("auto", "packed", "packed2"):  # small ensemble: one wavefront per chain; packed: the throughput kernels
+        if placement == "packed2":
+            if d > 10 or kind == "curve":
+                continue                                       # not a lane kernel: nothing parks a second chain
+            monkeypatch.setenv("GSSS_ONE_PER_LANE", "0")
+            placement = "packed"
         s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement=placement)
         if (kind == "vmf" and k <= 16 and d <= 256) or (kind == "curve" and d <= 256):
             assert s.mode == "fast"
