@@ -337,8 +337,8 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
     traffic, src = measured_traffic(name, n, S, thin, s.mode, layout)
     value = n * S * reps / dt
     # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
-    # (the curve targets mix over many hundreds of steps: thin 64, so that the 64 lags span 4096 steps)
-    ess_steps, ess_thin = (16384, 64) if name.startswith("curve") else ((2000, 8) if name.startswith("bingham") else (2000, 4))
+    # (the curve targets mix over a thousand steps and more: thin 128, so that the 64 lags span 8192 steps)
+    ess_steps, ess_thin = (32768, 128) if name.startswith("curve") else ((2000, 8) if name.startswith("bingham") else (2000, 4))
     ess_out = ess_per_sec(gs, s, pdf, value, n_steps=ess_steps, thin=ess_thin) if ess else None
     return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}",
             "stream": stream_description(d), "slice_steps": slice_steps, "sliced_fraction": round(sliced_frac, 4),
