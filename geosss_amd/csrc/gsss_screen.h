@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     bool timed_out = false;
     if (sliced) {
         int32_t len;
-        if (!SliceSched::take(a, kChunk, sched_word, chunk, s_begin, len, timed_out)) return;  // (one ticket per workgroup: never)
+        if (!SliceSched::take(a, a.one_per_lane ? kBlock : kChunk, sched_word, chunk, s_begin, len, timed_out)) return;  // (one ticket per workgroup: never)
         n_steps = s_begin + len;
     }
     const bool shrink = a.sampler == GSSS_SHRINK;
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         cur.t = 0;
         cur.status = (valid && n_steps > s_begin) ? kPending : kDone;
         if (sliced && valid) {
-            if (SliceSched::dead(a, kChunk)[cc] != 0) cur.status = kDone;  // stopped with an error flag in an earlier slice
+            if (SliceSched::dead(a, a.one_per_lane ? kBlock : kChunk)[cc] != 0) cur.status = kDone;  // stopped with an error flag in an earlier slice
             if (timed_out && cur.status != kDone) {                             // cannot happen (SliceSched::take)
                 cur.err |= GSSS_CHAIN_MAX_TRIES | GSSS_CHAIN_COUNTER_SATURATED;
                 cur.status = kDone;
@@ -984,7 +984,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         if (a.n_reject) put_out(&a.n_reject[c], a.n_reject[c] + ((int64_t)cur.n_try - (cur.steps_done - s_begin)));
         if (a.n_tries) put_out(&a.n_tries[c], a.n_tries[c] + (int64_t)cur.n_try);
         if (a.err && cur.err) put_out(&a.err[c], a.err[c] | cur.err);
-        if (sliced && cur.steps_done < n_steps) put_out(&SliceSched::dead(a, kChunk)[c], (int32_t)1);  // stopped early: stays stopped
+        if (sliced && cur.steps_done < n_steps) put_out(&SliceSched::dead(a, a.one_per_lane ? kBlock : kChunk)[c], (int32_t)1);  // stopped early: stays stopped
     };
 
     if (kPark) {  // the chain of slot 1 is initialised, set up and parked; then the chain of slot 0
@@ -1092,23 +1092,32 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
         }
     }
     int per_block = screen_parks<D, TP>() ? 2 * kBlock : kBlock;
-    // Mid-size ensembles: while one chain per lane still fits the chip in ONE round of workgroups, the second chain of a lane is
-    // worth less than a second wavefront somewhere else (tools/bench_placement.py).
+    // Small and mid-size ensembles run ONE chain per lane (256-chain workgroups, the lane's second slot empty): a second
+    // wavefront somewhere else is worth more than a lane's second chain, and rounds of workgroups half as long fill the chip
+    // more evenly.  Measured over the ensemble size (tools/bench_packing.py, 2000 steps per launch; r2 = rounds of workgroups
+    // with two chains per lane): one per lane wins or ties up to r2 ~ 1.35 for every kernel (README mixture, 1280 resident
+    // workgroups: 131 072 chains 1.8 -> 2.7e10 chain-steps/s, 327 680 2.9 -> 3.6e10, 458 752 3.3 -> 3.9e10, 786 432 3.8 -> 4.1e10);
+    // beyond, two per lane is 2-10 % ahead for the README kernel (917 504 .. 1 048 576 chains: 4.2-4.4 against 4.0-4.1e10) and
+    // within a few per cent either way for the others: two per lane from r2 = 1.35 on.
     bool one_per_lane = false;
-    const char *env_one = getenv("GSSS_ONE_PER_LANE");  // "0": always two chains per lane (tests run both packings)
+    SlicePlan plan;
+    int32_t first = 0;
+    const char *env_one = getenv("GSSS_ONE_PER_LANE");  // "0": always two chains per lane, "2": always one (tests, measurements)
     if (!(env_one && env_one[0] == '0') && screen_parks<D, TP>() && !REPLAY) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) == hipSuccess && per_cu >= 1 &&
-            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 1)
-            one_per_lane = (rb.n_chains + kBlock - 1) / kBlock <= (int64_t)per_cu * cus;
-        else
+        if (env_one && env_one[0] == '2')
+            one_per_lane = true;
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) == hipSuccess && per_cu >= 1 &&
+                 hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 1) {
+            const int64_t resident = (int64_t)per_cu * cus, b2 = (rb.n_chains + 2 * kBlock - 1) / (2 * kBlock);
+            one_per_lane = 20 * b2 < 27 * resident;
+        } else
             (void)hipGetLastError();
     }
     if (one_per_lane) per_block = kBlock;
     const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
     // a small last round of workgroups is cut into step slices (plan_partial_round, gsss_device.h)
-    int32_t first = 0;
-    const SlicePlan plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>() && !one_per_lane, st, first);
+    plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>(), st, first);
     RunBlock rbl = rb;
     rbl.one_per_lane = one_per_lane ? 1 : 0;
     rbl.sched = plan.ws;

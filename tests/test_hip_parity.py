@@ -861,7 +861,8 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
 @pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1280), ("vmfmix_k10_kappa500", 768), ("bingham_d10_vmax30", 768),
                                            ("vmfmix_d10_k5_kappa100", 512)])
 @pytest.mark.parametrize("sampler", ["shrink", "reject"])
-def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, sampler, monkeypatch):
+@pytest.mark.parametrize("per_lane", [2, 1])
+def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, sampler, per_lane, monkeypatch):
     """The lane kernels (two chains per lane) cut only a SMALL last round of workgroups into step slices
     (plan_partial_round, gsss_device.h): an ensemble of k x resident + a few workgroups gives the same bits -- states,
     retained rows, tries, rejections, error flags -- sliced or not, and a chain that stops in one slice stays stopped."""
@@ -869,7 +870,11 @@ def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, sampler, m
     z = golden(f"traj_{name}.npz")
     pdf = product_target(z)
     d = len(z["x0"])
-    n_chains = (resident + 37) * 512 - 100                      # one full round of workgroups + 37 more, the last one ragged
+    # one full round of workgroups + 37 more, the last one ragged; per_lane 1: an ensemble of half the size, which the library
+    # packs one chain per lane (256-chain workgroups)
+    n_chains = (resident + 37) * 256 * per_lane - 100
+    if per_lane == 2:
+        monkeypatch.setenv("GSSS_ONE_PER_LANE", "0")            # (an ensemble of this size would run one per lane as well)
     x0 = gs.sample_sphere_device(d - 1, n_chains, seed=43).T
     out = {}
     for label, env in (("whole", "0"), ("sliced", "128")):
@@ -950,10 +955,10 @@ def test_sliced_partial_round_long_hand_over_chain(gs, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["vmfmix_readme", "vmfmix_k10_kappa500", "bingham_d10_vmax30"])
-def test_one_chain_per_lane_equals_two(gs, name):
-    """Mid-size ensembles run the lane kernels with ONE chain per lane (twice the workgroups while they fit the chip in one round,
-    RunBlock::one_per_lane); large ones park a second chain per lane.  Chains are keyed by their id: the first 40 000 chains
-    of a 700 000-chain ensemble (two per lane) equal the same 40 000 run on their own (one per lane), bit for bit."""
+def test_one_chain_per_lane_equals_two(gs, name, monkeypatch):
+    """Small and mid-size ensembles run the lane kernels with ONE chain per lane (256-chain workgroups, RunBlock::one_per_lane);
+    large ones park a second chain per lane.  Chains are keyed by their id: the first 40 000 chains of a 700 000-chain ensemble
+    run two per lane (GSSS_ONE_PER_LANE=0) equal the same 40 000 run on their own (one per lane), bit for bit."""
     import torch
     z = golden(f"traj_{name}.npz")
     pdf = product_target(z)
@@ -962,6 +967,10 @@ def test_one_chain_per_lane_equals_two(gs, name):
     x0 = gs.sample_sphere_device(d - 1, n_big, seed=53).T
     out = {}
     for label, n in (("big", n_big), ("small", n_small)):
+        if label == "big":
+            monkeypatch.setenv("GSSS_ONE_PER_LANE", "0")
+        else:
+            monkeypatch.delenv("GSSS_ONE_PER_LANE")
         s = gs.ShrinkageSphericalSliceSampler(pdf, x0[:n].contiguous(), seed=10, mode="fast", placement="packed")
         assert _packed_kernel(s).startswith("screened_kernel")
         kept = s.advance(120, thin=40)

@@ -265,6 +265,7 @@ def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, monkey
     pdf = product_target(z)
     d = len(z["x0"])
     n_chains = (resident + 29) * 512 - 77
+    monkeypatch.setenv("GSSS_ONE_PER_LANE", "0")                 # two chains per lane, as the large ensembles run
     x0 = gs.sample_sphere_device(d - 1, n_chains, seed=15).T
     out = {}
     for label, env in (("whole", "0"), ("sliced", "128")):
