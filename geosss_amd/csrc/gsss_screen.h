@@ -987,7 +987,8 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         if (sliced && cur.steps_done < n_steps) put_out(&SliceSched::dead(a, a.one_per_lane ? kBlock : kChunk)[c], (int32_t)1);  // stopped early: stays stopped
     };
 
-    if (kPark) {  // the chain of slot 1 is initialised, set up and parked; then the chain of slot 0
+    if (kPark && !a.one_per_lane) {  // the chain of slot 1 is initialised, set up and parked; then the chain of slot 0
+        // (one_per_lane: the launch carries no LDS for parked chains)
         slot = 1;
         init();
         if (cur.status == kPending) setup();
@@ -1068,7 +1069,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     // mixture 76 bytes per chain and slice where 40 are due)
     if (kPark && slot == 1) trade();
     flush();
-    if (kPark) {
+    if (kPark && !a.one_per_lane) {
         trade();
         flush();
     }
@@ -1078,7 +1079,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
 template <int D, class TP, bool REPLAY>
 int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
 {
-    const size_t lds = screen_lds_doubles<D, TP, REPLAY>() * sizeof(double);
+    size_t lds = screen_lds_doubles<D, TP, REPLAY>() * sizeof(double);
     auto kern = screened_kernel<D, TP, REPLAY, false>;
     if constexpr (!REPLAY) {  // running statistics: a build of its own (the plain kernel carries none of it)
         if (rb.stats != nullptr) kern = screened_kernel<D, TP, false, true>;
@@ -1111,10 +1112,20 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
                  hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 1) {
             const int64_t resident = (int64_t)per_cu * cus, b2 = (rb.n_chains + 2 * kBlock - 1) / (2 * kBlock);
             one_per_lane = 20 * b2 < 27 * resident;
+            // ... and at ANY size where the LDS of the parked chains is what limits the workgroups per CU: without it more
+            // wavefronts are resident, and the hardware's switching between them beats the lanes' own between two chains
+            // (tools/bench_packing_shapes.py, 10^6 chains: vMF mixtures d = 10 K = 3 / 5 / 10 1.84 -> 2.35 / 1.62 -> 1.91 / 1.33 ->
+            // 1.60e10 chain-steps/s, d = 8 K = 3 2.09 -> 2.58e10; equal occupancy: two per lane ahead by up to 10 %)
+            int per_cu_one = 0;
+            if (!one_per_lane && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, kern, kBlock, (TP::lds_doubles() + kTabLds) * sizeof(double)) == hipSuccess)
+                one_per_lane = per_cu_one > per_cu;
         } else
             (void)hipGetLastError();
     }
-    if (one_per_lane) per_block = kBlock;
+    if (one_per_lane) {
+        per_block = kBlock;
+        lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
+    }
     const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
     // a small last round of workgroups is cut into step slices (plan_partial_round, gsss_device.h)
     plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>(), st, first);

@@ -858,8 +858,10 @@ def test_sliced_launch_equals_one_workgroup_per_chunk(gs, name, n_chains, sample
         assert int((err != 0).sum()) == 0
 
 
-@pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1280), ("vmfmix_k10_kappa500", 768), ("bingham_d10_vmax30", 768),
-                                           ("vmfmix_d10_k5_kappa100", 512)])
+@pytest.mark.parametrize("name,resident", [("vmfmix_readme", (1280, 1280)), ("vmfmix_k10_kappa500", (768, 768)), ("bingham_d10_vmax30", (768, 768)),
+                                           # (resident workgroups with two chains per lane, with one: without the LDS of parked
+                                           # chains the d = 10 mixture kernel fits three workgroups per CU instead of two)
+                                           ("vmfmix_d10_k5_kappa100", (512, 768))])
 @pytest.mark.parametrize("sampler", ["shrink", "reject"])
 @pytest.mark.parametrize("per_lane", [2, 1])
 def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, sampler, per_lane, monkeypatch):
@@ -872,6 +874,7 @@ def test_sliced_partial_round_of_the_lane_kernels(gs, name, resident, sampler, p
     d = len(z["x0"])
     # one full round of workgroups + 37 more, the last one ragged; per_lane 1: an ensemble of half the size, which the library
     # packs one chain per lane (256-chain workgroups)
+    resident = resident[2 - per_lane]
     n_chains = (resident + 37) * 256 * per_lane - 100
     if per_lane == 2:
         monkeypatch.setenv("GSSS_ONE_PER_LANE", "0")            # (an ensemble of this size would run one per lane as well)
