@@ -254,7 +254,8 @@ def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placem
 
 
 @pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1024), ("bingham_d10_vmax30", 512)])
-def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, monkeypatch):
+@pytest.mark.parametrize("per_lane", [2, 1])
+def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, per_lane, monkeypatch):
     """The statistics build of the lane kernels slices its last partial round like the plain build (plan_partial_round) and
     hands the accumulators from slice to slice with plain stores behind an agent-scope release: the same bits as unsliced."""
     import ctypes as C
@@ -264,8 +265,8 @@ def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, monkey
     z = golden(f"traj_{name}.npz")
     pdf = product_target(z)
     d = len(z["x0"])
-    n_chains = (resident + 29) * 512 - 77
-    monkeypatch.setenv("GSSS_ONE_PER_LANE", "0")                 # two chains per lane, as the large ensembles run
+    n_chains = (resident + 29) * 256 * per_lane - 77
+    monkeypatch.setenv("GSSS_ONE_PER_LANE", "0" if per_lane == 2 else "2")   # both packings of the lane kernels
     x0 = gs.sample_sphere_device(d - 1, n_chains, seed=15).T
     out = {}
     for label, env in (("whole", "0"), ("sliced", "128")):
