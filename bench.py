@@ -37,9 +37,14 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # PMC HBM bytes p
 
 README_MUS = 80.0 * np.array([[0.87, -0.37, 0.33], [-0.20, -0.89, -0.40], [0.19, 0.22, -0.96]])
 
-# (workload, chains per GPU): the BASELINE configs other than the headline one
+# (workload, chains per GPU): the BASELINE configs other than the headline one; cfg4 as the survey
+# wrote it: kappa = 800 at d = 10 / 50 / 200 (sh/submit_job_curve_varying_ndim.sh:5), kappa = 500 at d = 10 (scripts/curve_vMF.py:495
+# default) and d = 24, the overlap with the reference's own sweep (sh/submit_job_curve_varying_ndim.sh:11)
 EXTRA_CONFIGS = [("bingham_d10", 1_000_000), ("curve_d10", 100_000), ("curve_d50", 100_000), ("curve_d200", 100_000),
-                 ("vmfmix_k10_kappa500", 1_000_000)]
+                 ("curve_d10_kappa500", 100_000), ("curve_d24", 100_000), ("vmfmix_k10_kappa500", 1_000_000)]
+# ... and the headline target on NUMPY'S OWN STREAM (rng="numpy": PCG64 + ziggurat per chain, the reference's arithmetic and
+# draw order, mcmc.py:382-401 from the seed) -- the path that reproduces the reference's chains from (pdf, x0, seed) at 1e-10
+NUMPY_STREAM_CONFIG = ("vmfmix_readme", 1_000_000)
 
 
 def make_target(gs, name):
@@ -54,13 +59,14 @@ def make_target(gs, name):
         return gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=True, seed=6982), 50
     if name == "bingham_d50_dense":
         return gs.random_bingham(d=50, vmax=300.0, vmin=0.0, eigensystem=False, seed=6982), 50
-    if name.startswith("curve_d"):
-        d = int(name[len("curve_d"):])
-        return gs.CurvedVonMisesFisher(gs.SlerpCurve(gs.brownian_curve(10, d, 0.5, seed=4562)), 800.0), d
+    if name.startswith("curve_d"):  # curve_d<d>[_kappa<k>]
+        parts = name[len("curve_d"):].split("_kappa")
+        d, kappa = int(parts[0]), float(parts[1]) if len(parts) > 1 else 800.0
+        return gs.CurvedVonMisesFisher(gs.SlerpCurve(gs.brownian_curve(10, d, 0.5, seed=4562)), kappa), d
     raise ValueError(name)
 
 
-def algorithmic_flops(name, d, tries_per_step):
+def algorithmic_flops(name, d, tries_per_step, rng="philox"):
     """FP64 flops (FMA = 2) of the restricted-form algorithm per chain-step, counted from the kernels'
     arithmetic (DESIGN.md "Roofline"): per step the d normals (one Box-Muller pair = 80: log 40, sincos 36,
     sqrt + scalings), the projection (3 dots, 2 axpys, 2 rsqrt-scalings = 10 d + 20), the coefficients of the
@@ -69,8 +75,10 @@ def algorithmic_flops(name, d, tries_per_step):
     the orthonormal basis of the tangent plane (22) and the combination (9) instead of two pairs and the projection."""
     pairs = (d + 1) // 2
     setup = 80.0 if d == 3 else 80.0 * pairs + 10.0 * d + 20.0
+    if rng == "numpy":  # the reference's set-up: d ziggurat normals (common path: a product and a compare, ~4 each) and the projection
+        setup = 4.0 * d + 10.0 * d + 20.0
     if name.startswith("vmfmix"):
-        k = 3 if name == "vmfmix_readme" else 10
+        k = 3 if name.startswith("vmfmix_readme") else 10
         setup += 4.0 * k * d + 34.0 * k              # K dots with x and u; K exps for the level of x
         if k >= 5:  # screened accept test: one double exp of the largest term, K single-precision 2^x bounds
             per_try = 36.0 + 4.0 * k + k + 34.0 + 4.0 * k + 6.0
@@ -99,6 +107,8 @@ def oracle_target(orc, gs, name):
 REFERENCE_NAMES = {"vmfmix_readme": "vmfmix_readme", "vmfmix_k10_kappa500": "vmfmix_k10_kappa500",
                    "bingham_d10": "bingham_d10_vmax30", "curve_d10": "curve_d10_kappa800",
                    "curve_d200": "curve_d200_kappa800"}
+STREAM_NUMPY = ("numpy PCG64 + ziggurat, one generator per chain (SeedSequence(seed).spawn(n_chains)): the reference's arithmetic and "
+                "draw order -- d normals projected onto the tangent plane, then the uniforms (mcmc.py:387-395)")
 
 
 # What the library's counter-based stream draws per step: said in the bench line so that nobody reads
@@ -113,17 +123,41 @@ def stream_description(d):
     return STREAM_S2 if d == 3 else STREAM_D
 
 
-def issue_counters(workload, n, S, thin, mode, layout="chains"):
-    """Issue-side counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/pmc_traffic.py), quoted only when this run's launch has the profiled shape: how busy the vector pipes were, how many
-    wavefronts were resident, and the FP64 flops the kernel actually ISSUED against the FP64 peak."""
+_digest = None
+
+
+def source_digest():
+    """sha256 of the kernel sources this tree was built from (geosss_amd.build.source_digest)."""
+    global _digest
+    if _digest is None:
+        from geosss_amd import build
+        _digest = build.source_digest()
+    return _digest
+
+
+def profile_record(workload, n, S, thin, mode, layout):
+    """The committed rocprofv3 PMC record of a workload (profiles/traffic.json, written by tools/pmc_traffic.py) -- or why it
+    cannot be quoted: (record, None) when this run's launch has the profiled shape AND the kernel sources are the ones the
+    profile was taken of (sha256 over geosss_amd/csrc + include/gsss.h), else (None, "absent" | "other launch shape" | "stale")."""
     try:
         rec = json.load(open(TRAFFIC_FILE))[workload]
     except (OSError, KeyError, ValueError):
-        return {}
+        return None, "absent"
     shape = rec.get("launch", {})
     if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode"), shape.get("layout", "components")) != (n, S, thin, mode, layout):
-        return {}
+        return None, "other launch shape"
+    if rec.get("csrc_sha256") != source_digest():
+        return None, "stale"
+    return rec, None
+
+
+def issue_counters(workload, n, S, thin, mode, layout="chains"):
+    """Issue-side counters of the dominant kernel from the committed rocprofv3 PMC passes, quoted only when this run's launch
+    has the profiled shape and sources: how busy the vector pipes were, how many wavefronts were resident, and the FP64 flops
+    the kernel actually ISSUED against the FP64 peak."""
+    rec, why = profile_record(workload, n, S, thin, mode, layout)
+    if rec is None:
+        return {"counters": why}
     out = dict(rec.get("issue", {}))
     if out:
         out["valu_busy_meaning"] = ("4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): VALU-active wavefront cycles per SIMD "
@@ -131,19 +165,20 @@ def issue_counters(workload, n, S, thin, mode, layout="chains"):
     return out
 
 
-def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms, layout="chains"):
+def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms, layout="chains"):  # name: workload[__numpy_stream]
     """Delivered-work figure: the FP64 flops of the ALL-DOUBLE restricted-form algorithm whose decisions the kernel reproduces
     (algorithmic_flops) over the kernel time and the FP64 vector peak.  NOT a hardware utilisation: most per-try flops are
     executed in single precision; `fp64_issued_frac` and `valu_busy` are the hardware's own counters."""
-    flops = algorithmic_flops(name, d, tps)
+    flops = algorithmic_flops(name, d, tps, rng="numpy" if name.endswith("__numpy_stream") else "philox")
     out = {"bound": "fp64_valu", "achieved": flops * n * S / (kern_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
            "frac": flops * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "flops_per_chain_step": flops,
            "meaning": "algorithmic FP64 flops of the all-double algorithm / kernel time / FP64 vector peak: delivered work, not "
                       "hardware utilisation (see fp64_issued_frac, valu_busy)"}
     iss = issue_counters(name, n, S, thin, mode, layout)
-    for k in ("fp64_issued_frac", "valu_busy", "resident_waves_per_simd", "valu_insts_per_chain_step", "lane_activity"):
+    for k in ("fp64_issued_frac", "valu_busy", "valu_busy_meaning", "resident_waves_per_simd", "valu_insts_per_chain_step", "lane_activity"):
         out[k] = iss.get(k)
     out["counters_source"] = iss.get("source")
+    out["counters"] = iss.get("counters", "profiles/traffic.json, same launch shape and kernel sources")
     return out
 
 
@@ -214,13 +249,26 @@ def ess_per_sec(gs, sampler, pdf, steps_per_sec_total, n_steps=4000, thin=4, lag
     accumulate the lag sums of the first coordinate per chain (gsss_run_args.stats_dev; no draws are stored -- at
     10^6 chains x 4000 steps they would be 96 GB) and the reference's own estimator (utils.acf + the IAT heuristic,
     geosss/utils.py:96-134, on the series thinned by `thin`) gives n_eff per chain; plus the mode occupancy."""
+    from geosss_amd import diagnostics as dg
     sampler.enable_stats(lags=lags, second_moment=False)
     sampler.advance(n_steps, thin=thin, keep=False)
     r = sampler.stats()
     rel = float((r["n_eff"] / r["n"]).mean().item()) / thin        # effective draws per chain-step
     trunc = float(r["iat_truncated"].double().mean().item())
+    # the same heuristic on the autocorrelation AVERAGED over the chains (no per-chain noise, no Jensen gap of mean(1 / IAT))
+    iat_pooled = float(dg.iat_from_acf(r["acf"].mean(0, keepdim=True))[0].item()) * thin
+    # and with no window at all: the chains are independent and (after the timed launches) stationary, so the spread of their
+    # means measures tau directly (diagnostics.ess_between_chains)
+    bc = dg.ess_between_chains(r["proj_mean"], r["n"], r["proj_var"])
+    tau_steps = bc["tau"] * thin
     out = {"ess_per_step": rel, "ess_per_sec": rel * steps_per_sec_total,
            "iat_truncated_frac": trunc,  # chains whose pair sums never went negative within the lags: their IAT is a lower bound
+           "ess_per_step_is": "estimate" if trunc < 0.02 else "upper bound: the lag window cuts the autocorrelation of a share of the chains (between_chains is the estimate)",
+           "iat_steps_pooled_acf": iat_pooled,
+           "between_chains": {"tau_steps": tau_steps, "ess_per_step": 1.0 / tau_steps, "ess_per_sec": steps_per_sec_total / tau_steps,
+                              "rel_se": bc["rel_se"], "chains": bc["chains"], "steps_per_chain": n_steps,
+                              "estimator": "tau = n Var_chains(chain mean) / Var(x) over all chains of the launch (independent, stationary): "
+                                           "no lag window; finite-length bias ~ -tau / n"},
            "estimator": f"geosss IAT heuristic on the running autocorrelation of the first coordinate (lags <= {lags} x {thin} "
                         f"steps), all {sampler.n_chains} chains x {n_steps} steps, no stored draws"}
     if "mode_occupancy" in r:
@@ -232,24 +280,42 @@ def measured_traffic(workload, n, S, thin, mode, layout="chains"):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); only quoted when this
     run's launch has the shape the profile was taken with."""
-    try:
-        rec = json.load(open(TRAFFIC_FILE))[workload]
-    except (OSError, KeyError, ValueError):
-        return None, None
-    shape = rec.get("launch", {})
-    if (shape.get("chains"), shape.get("steps"), shape.get("thin"), shape.get("mode"), shape.get("layout", "components")) != (n, S, thin, mode, layout):
-        return None, None
+    rec, why = profile_record(workload, n, S, thin, mode, layout)
+    if rec is None:
+        return None, f"counters: {why}"
     return rec["bytes_per_launch"], rec["source"]
 
 
-def hbm_bytes_per_step(d, thin, S, slice_steps=0, sliced_fraction=1.0):
-    """Algorithmic HBM bytes per chain-step: retained sample 8d/thin + state load and
-    store 16d/S + the two int64 counters read-modify-written per launch 32/S; the SLICED share of a launch (DESIGN.md section
-    5.4: every chain of a group kernel, the last partial round of a lane kernel) hands state and counters over through HBM
-    once per slice: for that share S is the slice length."""
-    hand_over = 16.0 * d + 32.0
-    f = sliced_fraction if slice_steps > 0 else 0.0
-    return 8.0 * d / thin + (1.0 - f) * hand_over / S + f * hand_over / min(S, max(slice_steps, 1))
+def hbm_bytes_per_step(d, thin, S):
+    """ALGORITHMIC HBM bytes per chain-step, SURVEY.md section 8(d): the retained sample 8 d / thin plus the state load and
+    store and the counter words amortised over the S steps of a launch, (16 d + 16) / S."""
+    return 8.0 * d / thin + (16.0 * d + 16.0) / S
+
+
+def handover_bytes_per_step(d, S, slice_steps=0, sliced_fraction=0.0):
+    """What the library's own scheduling adds: the SLICED share of a launch hands state (16 d), the two
+    64-bit counters (read and written: 32) over through HBM once per slice instead of once per launch.  Traffic,
+    not algorithm: reported beside the algorithmic bytes, never inside them."""
+    if slice_steps <= 0 or sliced_fraction <= 0.0:
+        return 0.0
+    return sliced_fraction * (16.0 * d + 32.0) * (1.0 / min(S, slice_steps) - 1.0 / S)
+
+
+def hbm_roofline(d, thin, S, n, kern_ms, slice_steps, sliced_frac, traffic, traffic_src, note=None):
+    """The `roofline` object of a bench line: `achieved` / `frac` from the ALGORITHMIC bytes of SURVEY.md section 8(d) alone;
+    the hand-over of sliced launches and the counters' total beside them."""
+    alg = hbm_bytes_per_step(d, thin, S) * n * S
+    hand = handover_bytes_per_step(d, S, slice_steps, sliced_frac) * n * S
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes": alg, "handover_bytes": hand, "traffic": traffic,
+           "traffic_ratio": (traffic / alg) if traffic else None, "traffic_source": traffic_src,
+           "bytes_meaning": "algorithmic_bytes = (8 d / thin + (16 d + 16) / S) x chain-steps of a launch (SURVEY.md section 8(d)); "
+                            "handover_bytes = state and counters of the sliced share of the launch passed from slice to slice "
+                            "through HBM (self-inflicted, not in `achieved`); traffic = 2 x FETCH_SIZE + WRITE_SIZE of the PMC passes"}
+    if note:
+        out["note"] = note
+    return out
 
 
 def last_slice_steps(gs):
@@ -302,15 +368,21 @@ def kept_buffer(torch, layout, n, S, thin, d):
     return torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda"), dict()
 
 
-def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
-    """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload."""
+def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="philox"):
+    """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload.  rng="numpy": the same launch
+    on numpy's own stream, one generator per chain, packed (fast_kernel<..., NUMPY>)."""
     pdf, d = make_target(gs, name)
     x0 = gs.sample_sphere_device(d - 1, n, seed=0)
-    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed)
+    kw_s = dict(rng="numpy", placement="packed") if rng == "numpy" else {}
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed, **kw_s)
     thin = 100
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
-    layout = pick_layout(layout, lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(), d, thin)
+    variant = gs._lib.VARIANT_FAST_DOUBLE if rng == "numpy" else 0   # (the name of the kernel that serves numpy's stream: the all-double lane kernel)
+    kernel = lib.gsss_kernel_name(s._target_dev.handle, mode_id, variant, 1).decode()
+    if rng == "numpy":
+        kernel = kernel.replace(">>", ">, NUMPY>") if kernel.startswith("fast_kernel") else kernel
+    layout = pick_layout(layout, kernel, d, thin)
     kept, kw = kept_buffer(torch, layout, n, S, thin, d)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -330,26 +402,24 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto"):
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     tps = (int(s._n_tries.sum().item()) - tries0) / (n * S * reps)
-    lib = gs._lib.load()
-    mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
     slice_steps, sliced_frac = last_slice_steps(gs)
-    bytes_launch = hbm_bytes_per_step(d, thin, S, slice_steps, sliced_frac) * n * S
-    traffic, src = measured_traffic(name, n, S, thin, s.mode, layout)
+    wl_key = name + ("__numpy_stream" if rng == "numpy" else "")
+    traffic, src = measured_traffic(wl_key, n, S, thin, s.mode, layout)
     value = n * S * reps / dt
     # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
     # (the curve targets mix over a thousand steps and more: thin 128, so that the 64 lags span 8192 steps)
     ess_steps, ess_thin = (32768, 128) if name.startswith("curve") else ((2000, 8) if name.startswith("bingham") else (2000, 4))
-    ess_out = ess_per_sec(gs, s, pdf, value, n_steps=ess_steps, thin=ess_thin) if ess else None
-    return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}",
-            "stream": stream_description(d), "slice_steps": slice_steps, "sliced_fraction": round(sliced_frac, 4),
+    ess_out = ess_per_sec(gs, s, pdf, value, n_steps=ess_steps, thin=ess_thin) if ess and rng != "numpy" else None
+    return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}"
+                        + (", rng=numpy (one PCG64 generator per chain), packed" if rng == "numpy" else ""),
+            "stream": STREAM_NUMPY if rng == "numpy" else stream_description(d), "slice_steps": slice_steps,
+            "sliced_fraction": round(sliced_frac, 4),
             "value": value, "unit": "chain-steps/s", "launches": reps, "mode": s.mode, "ess": ess_out,
-            "kernel": lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode(),
+            "kernel": kernel,
             "kernel_ms": kern_ms, "tries_per_step": tps, "chains_in_error": int((s._err != 0).sum().item()),
-            "roofline": {"bound": "hbm", "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": src},
+            "roofline": hbm_roofline(d, thin, S, n, kern_ms, slice_steps, sliced_frac, traffic, src),
             "kept_rows_layout": layout,
-            "roofline_valu": roofline_valu(name, d, tps, n, S, thin, s.mode, kern_ms, layout)}
+            "roofline_valu": roofline_valu(wl_key, d, tps, n, S, thin, s.mode, kern_ms, layout)}
 
 
 def main(argv=None):
@@ -486,8 +556,6 @@ def main(argv=None):
 
     if rank == 0:
         slice_steps, sliced_frac = last_slice_steps(gs)
-        bytes_per_launch = hbm_bytes_per_step(d, thin, S, slice_steps, sliced_frac) * n * S
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
         traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode, layout)
@@ -501,17 +569,17 @@ def main(argv=None):
                        "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
                        "sliced_fraction": round(sliced_frac, 4),
                        "kept_rows_layout": layout,
+                       "csrc_sha256": source_digest(),
                        "mode": sampler.mode,
                        "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
                        "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"
                        if world > 1 else "single GPU"},
             "tries_per_step": tries / total_steps, "chains_in_error": bad,
             "kernel_ms": kern_ms, "rccl": rccl,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "chain state lives in registers/LDS for the whole launch, so HBM sees only the "
-                                 "state load/store, counters and the thinned sample; the kernel is bound by FP64 VALU "
-                                 "issue (see roofline_valu and DESIGN.md)"},
+            "roofline": hbm_roofline(d, thin, S, n, kern_ms, slice_steps, sliced_frac, traffic, traffic_src,
+                                     note="chain state lives in registers/LDS for the whole launch, so HBM sees only the "
+                                          "state load/store, counters and the thinned sample; the kernel is bound by vector "
+                                          "issue (see roofline_valu and DESIGN.md)"),
             "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms, layout),
         }
         if world == 1 and not args.no_ess:
@@ -519,6 +587,7 @@ def main(argv=None):
         if world == 1 and not args.no_configs and args.workload == "vmfmix_readme":
             del sampler, kept
             out["configs"] = [time_config(gs, torch, name, nc, S, layout=args.layout) for name, nc in EXTRA_CONFIGS]
+            out["configs"].append(time_config(gs, torch, *NUMPY_STREAM_CONFIG, S, layout=args.layout, rng="numpy"))
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "gsss_variant_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "gsss_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "gsss_sample_sphere": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
+    "gsss_tangent_s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "gsss_rows_to_components": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),
     "gsss_components_to_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),
     "gsss_samples_to_chains": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),

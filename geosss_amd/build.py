@@ -102,6 +102,19 @@ def build(force=False, jobs=None, extra=(), verbose=True, out=None):
     return lib
 
 
+def source_digest():
+    """sha256 over the kernels' sources (csrc/*.h, *.hip, *.inc and include/gsss.h, by name): what a profile was taken of.
+    bench.py quotes the committed rocprofv3 counters (profiles/traffic.json) only for the sources they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hip", ".inc"))]
+    files.append(os.path.join(HERE, "..", "include", "gsss.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def resource_usage(src, extra=()):
     """hipcc's -Rpass-analysis=kernel-resource-usage remarks of one translation unit (device code only, nothing written):
     {mangled kernel name: {"vgprs", "sgprs", "scratch", "occupancy", "lds"}}."""

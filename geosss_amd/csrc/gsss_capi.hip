@@ -238,6 +238,54 @@ __global__ void __launch_bounds__(kBlock) sample_sphere_kernel(uint64_t seed, ui
     for (int j = 0; j < d; ++j) out[(size_t)j * n + c] = out[(size_t)j * n + c] / nrm;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The S^2 tangent draw of the Philox stream, exposed for verification (gsss_tangent_s2): the very expressions the set-up of a
+// step evaluates (screened_kernel / fast_kernel / wave_kernel: x.x, inv_norm, x / |x|, PhiloxDraws::tangent -> tangent3) for
+// given states and angle words.  out[c][0..2] = n = x / |x|, [3..5] = b1 (the tangent at angle 0), [6..8] = b2 (at a quarter
+// turn), [9..11] = the tangent for word w[c].  tab: the table-driven sincos of the throughput kernels, else the exact kernels'.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) tangent_s2_kernel(const double *__restrict__ x, const uint32_t *__restrict__ w, int64_t n,
+                                                            int tab_driven, double *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) double lds[kTabLds + 2];
+    const fm::Tables tab = stage_tables(lds);
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= n) return;
+    using V = LaneVec<3>;
+    const double xs[3] = {x[3 * c], x[3 * c + 1], x[3 * c + 2]};
+    const double xx = vdot<V>(xs, xs);
+    double nrm[3];
+    if (tab_driven) {  // gsss_screen.h / gsss_fast.h: x * rsqrt(x.x)
+        const double rnx = inv_norm(xx);
+        for (int j = 0; j < 3; ++j) nrm[j] = xs[j] * rnx;
+    } else {           // run_kernel (gsss_device.h): x / (|x| + 1e-100), sphere.py:14
+        const double nx = sqrt(xx) + 1e-100;
+        for (int j = 0; j < 3; ++j) nrm[j] = xs[j] / nx;
+    }
+    double u[3], b1[3], b2[3];
+    if (tab_driven) {
+        PhiloxDraws<V, true> dr;
+        dr.tab = tab;
+        dr.d = 3;
+        dr.tangent(nrm, u, 0, w[c]);
+    } else {
+        PhiloxDraws<V, false> dr;
+        dr.d = 3;
+        dr.tangent(nrm, u, 0, w[c]);
+    }
+    tangent3(nrm[0], nrm[1], nrm[2], 0.0, 1.0, b1[0], b1[1], b1[2]);
+    tangent3(nrm[0], nrm[1], nrm[2], 1.0, 0.0, b2[0], b2[1], b2[2]);
+    double *o = out + 12 * c;
+    for (int j = 0; j < 3; ++j) {
+        o[j] = nrm[j];
+        o[3 + j] = b1[j];
+        o[6 + j] = b2[j];
+        o[9 + j] = u[j];
+    }
+}
+
 }  // namespace gsss
 
 namespace gsss {
@@ -724,6 +772,22 @@ int gsss_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int32_t 
     const int64_t grid = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(sample_sphere_kernel, dim3((unsigned)grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        seed, chain_offset, n, (int)d, state_dev);
+    GSSS_HIP_TRY(hipGetLastError());
+    return GSSS_OK;
+}
+
+int gsss_tangent_s2(const double *x_dev, const uint32_t *w_dev, int64_t n, int32_t table_driven, double *out_dev, int device, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x_dev || !w_dev || !out_dev))) {
+        set_error("bad argument to gsss_tangent_s2");
+        return GSSS_E_INVALID;
+    }
+    if (n == 0) return GSSS_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    const int64_t grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(tangent_s2_kernel, dim3((unsigned)grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), x_dev, w_dev, n,
+                       (int)table_driven, out_dev);
     GSSS_HIP_TRY(hipGetLastError());
     return GSSS_OK;
 }

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 __all__ = ["acf", "acf_fft", "IAT", "n_eff", "distance", "hopping_frequency", "mode_occupancy", "mode_kl", "from_running",
-           "iat_from_acf", "ess_bulk"]
+           "iat_from_acf", "ess_bulk", "ess_between_chains"]
 
 
 def _t(x):
@@ -192,6 +192,8 @@ def from_running(acc, d, n_modes, n_lags, second_moment=True):
     out["hopping_frequency"] = acc[r_hop] / (n - 1)
     if n_modes:
         out["mode_occupancy"] = (acc[r_mode:r_mode + n_modes] / n).T
+    out["proj_mean"] = acc[r_p] / n                                            # mean and (biased) variance of p = x . w per chain
+    out["proj_var"] = acc[r_p + 1] / n - out["proj_mean"] ** 2
     if n_lags:
         L = n_lags
         if bool((n <= L).any()):
@@ -213,6 +215,38 @@ def from_running(acc, d, n_modes, n_lags, second_moment=True):
         out["n_eff"] = n / out["iat"]
         out["iat_truncated"] = ~pair_sum_went_negative(ac)
     return out
+
+
+def ess_between_chains(chain_means, n, chain_vars):
+    """Integrated autocorrelation time and effective sample size of a scalar quantity from MANY independent stationary chains,
+    with no lag window at all: for a stationary chain Var(mean of n draws) = Var(x) tau_n / n with
+    tau_n = 1 + 2 sum_{k<n} (1 - k/n) rho_k -> tau, so over C chains of n draws each
+
+        tau = n Var_c(mean_c) / Var(x),      ESS per chain = n / tau = Var(x) / Var_c(mean_c),
+
+    Var(x) = the pooled variance of all draws = mean_c(within-chain variance) + Var_c(mean_c) (law of total variance).
+    Inputs per chain: the mean, the number of draws and the (biased, 1/n) variance of the series -- `proj_mean`, `n`,
+    `proj_var` of `from_running`, i.e. the sums the sampler kernels already keep.  What the windowed estimators
+    (geosss/utils.py:109-134 IAT / n_eff on a truncated autocorrelation) can only bound from below when the chain mixes
+    slower than the window, this measures -- to a relative standard error sqrt(2 / (C - 1)) -- provided the chains ARE
+    independent and stationary (start them from draws of the target, or burn in several tau) and n >> tau (the finite-n
+    factor (1 - k/n) biases tau low by ~ tau / n otherwise).  Returns a dict of floats:
+    tau (in retained draws), ess_per_chain, ess_total, rel_se, n, chains."""
+    m, v = _t(chain_means).to(torch.float64).reshape(-1), _t(chain_vars).to(torch.float64).reshape(-1)
+    nn = _t(n).to(torch.float64).reshape(-1)
+    if m.numel() < 2:
+        raise ValueError("the between-chain estimator needs at least two chains")
+    if float(nn.max() - nn.min()) != 0.0:
+        raise ValueError("the between-chain estimator takes chains of equal length")
+    n_draws = float(nn[0])
+    between = float(m.var(unbiased=True))
+    total = float(v.mean()) + between
+    if not between > 0.0 or not total > 0.0:
+        return {"tau": float("nan"), "ess_per_chain": float("nan"), "ess_total": float("nan"), "rel_se": float("nan"),
+                "n": n_draws, "chains": int(m.numel())}
+    tau = n_draws * between / total
+    return {"tau": tau, "ess_per_chain": n_draws / tau, "ess_total": m.numel() * n_draws / tau,
+            "rel_se": float(np.sqrt(2.0 / (m.numel() - 1))), "n": n_draws, "chains": int(m.numel())}
 
 
 def _average_ranks(flat):

@@ -270,6 +270,16 @@ const char *gsss_kernel_name(const gsss_target *t, int32_t mode, int32_t variant
 int gsss_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int32_t d, double *state_dev, int device,
                        void *stream);
 
+/* Verification of the library stream's set-up on S^2 (d = 3).  The reference draws z ~ N(0, I_3) and takes
+ * u = sphere.spherical_projection(z, x) (mcmc.py:387, sphere.py:29-33): a uniformly distributed unit tangent at x.  The Philox
+ * stream draws that tangent directly from ONE 32-bit word w: u = cos(phi) b1 + sin(phi) b2, phi = 2 pi w / 2^32, in a fixed
+ * orthonormal basis (b1, b2) of the tangent plane at n = x / |x|.  This entry point evaluates exactly what the sampler kernels
+ * evaluate there, for n points: x_dev [n][3] states (any norm), w_dev [n] angle words -> out_dev [n][12] = n, b1, b2, u.
+ * table_driven != 0: the sincos of the throughput kernels (screened / fast / one-wavefront), 0: the exact kernels'.
+ * tests/test_hip_tangent.py holds it to the reference's own tangents (tests/golden/tangent_kat.npz). */
+int gsss_tangent_s2(const double *x_dev, const uint32_t *w_dev, int64_t n, int32_t table_driven, double *out_dev, int device,
+                    void *stream);
+
 /* Layout changes between numpy's row-major arrays and the component-major device layout.
  *   gsss_rows_to_components: in [n][d]            -> out [d][n]
  *   gsss_components_to_rows: in [d][n]            -> out [n][d]

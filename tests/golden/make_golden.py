@@ -294,19 +294,41 @@ def make_geometry_kat():
     save("geometry_kat.npz", **arrays)
 
 
+def make_tangent_kat():
+    """What the set-up of a step draws on S^2, from the reference: pairs (x, u = sphere.spherical_projection(z, x)) with
+    z ~ N(0, I_3) (mcmc.py:387, sphere.py:29-33) -- x unit, non-unit (|x| = 0.998: the sampler never renormalises its
+    state) and at the two poles, where the tangent basis of the device's direct draw changes its formula.  The GPU test
+    expresses these u in the device's tangent basis at x and holds their angles to the uniform law the library's
+    one-angle draw assumes.  10^5 pairs; x is stored for the first 8 * 10^4 only (the poles are +-e_z)."""
+    rng = np.random.default_rng(20261004)
+    n_unit, n_short, n_pole = 60000, 20000, 10000
+    x = rsphere.radial_projection(rng.standard_normal((n_unit + n_short, 3)))
+    x[n_unit:] *= 0.998
+    xs = np.concatenate([x, np.tile([0.0, 0.0, 1.0], (n_pole, 1)), np.tile([0.0, 0.0, -1.0], (n_pole, 1))])
+    z = rng.standard_normal(xs.shape)
+    u = np.array([rsphere.spherical_projection(zi, xi) for zi, xi in zip(z, xs)])  # one call per pair, as the sampler makes it
+    assert np.max(np.abs(np.linalg.norm(u, axis=1) - 1.0)) < 1e-14
+    assert np.max(np.abs(np.sum(u * xs, axis=1))) < 1e-12  # (cancellation when z is nearly parallel to x)
+    save("tangent_kat.npz", x=x, u=u, n_unit=np.int64(n_unit), n_short=np.int64(n_short), n_pole=np.int64(n_pole))
+
+
 def _stat_chain(args):
     name, seed_state, n_steps, burn = args
     pdf, x0, _, _ = cases()[name]
     ss = np.random.SeedSequence(entropy=seed_state[0], spawn_key=seed_state[1])
     s = gs.ShrinkageSphericalSliceSampler(pdf, np.array(x0), ss)
-    X = s.sample(n_steps + burn, burnin=0)
-    rej_total = s.n_reject
-    X = X[burn:]
+    s.sample(burn + 1, burnin=0)          # `burn` transitions
+    rej_burn = s.n_reject
+    X = s.sample(n_steps, burnin=0)       # row 0 = the state after burn-in, n_steps - 1 further transitions: the same chain as
+    rej_total = s.n_reject                # one sample(n_steps + burn) call, rows [burn:]
     geo = np.arccos(np.clip(np.sum(X[1:] * X[:-1], axis=-1), -1, 1))
     from geosss.utils import IAT
     out = dict(iat=np.array([IAT(X[:, j]) for j in range(X.shape[1])]),  # per chain and coordinate, utils.py:119-131
-               mean=X.mean(0), second=(X[:, :, None] * X[:, None, :]).mean(0), rej_per_step=rej_total / (n_steps + burn - 1),
+               mean=X.mean(0), rej_per_step=rej_total / (n_steps + burn - 1),
+               rej_per_step_post=(rej_total - rej_burn) / (n_steps - 1),  # rejections per step after burn-in only
                geo_step=geo.mean(), logp_mean=np.mean(pdf.log_prob(X)) if name.startswith(("vmf", "bing")) else np.nan)
+    if X.shape[1] <= 16:  # (d (d + 1) / 2 numbers per chain: left out for the d = 50 / 200 curves)
+        out["second"] = (X[:, :, None] * X[:, None, :]).mean(0)
     if name.startswith("vmfmix"):
         modes = np.array([p.mu / np.linalg.norm(p.mu) for p in pdf.pdfs])
         occ = np.bincount(np.argmax(X @ modes.T, axis=1), minlength=len(modes)) / len(X)
@@ -314,19 +336,21 @@ def _stat_chain(args):
     return out
 
 
-def make_stats():
+def make_stats(plan=None):
     from concurrent.futures import ProcessPoolExecutor
 
-    plan = {"vmfmix_readme": 12000, "vmfmix_k10_kappa500": 8000, "bingham_d10_vmax30": 60000,
-            "curve_d10_kappa800": 4000}
-    for name, n_steps in plan.items():
+    # name -> (steps kept, burn-in steps before them)
+    plan = plan or {"vmfmix_readme": (12000, 1200), "vmfmix_k10_kappa500": (8000, 800), "bingham_d10_vmax30": (60000, 6000),
+                    "curve_d10_kappa800": (4000, 400)}
+    for name, (n_steps, burn) in plan.items():
         t0 = time.time()
         seeds = np.random.SeedSequence(48385).spawn(8)  # scripts/bingham.py:87-88 pattern
-        jobs = [(name, (s.entropy, s.spawn_key), n_steps, n_steps // 10) for s in seeds]
+        jobs = [(name, (s.entropy, s.spawn_key), n_steps, burn) for s in seeds]
         with ProcessPoolExecutor(8) as ex:
             res = list(ex.map(_stat_chain, jobs))
         arrays = {k: np.array([r[k] for r in res]) for k in res[0]}
         arrays["n_steps"] = np.int64(n_steps)
+        arrays["burn"] = np.int64(burn)
         arrays["n_chains"] = np.int64(len(res))
         print(f"stats {name}: rej/step={arrays['rej_per_step'].mean():.3f} geo={arrays['geo_step'].mean():.3f} "
               f"({time.time() - t0:.0f}s)")
@@ -654,3 +678,7 @@ if __name__ == "__main__":
         make_geometry_kat()
     if "stats" in what:
         make_stats()
+    if "tangent" in what:
+        make_tangent_kat()
+    if "stats_cfg4" in what:  # round 4: cfg4's other two dimensions, 8 chains x 5000 steps after 3000 of burn-in
+        make_stats({"curve_d50_kappa800": (5000, 3000), "curve_d200_kappa800": (5000, 3000)})

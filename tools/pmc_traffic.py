@@ -46,6 +46,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
     thin = int(re.search(r"thin=(\d+)", cfg.get("workload", "thin=0")).group(1))
     out[wl] = {"kernel": name.split("(")[0].replace("void ", ""), "fetch_size_kib": fetch, "write_size_kib": write,
                "bytes_per_launch": (2 * fetch + write) * 1024.0,
+               "csrc_sha256": cfg.get("csrc_sha256"),  # the kernel sources the counters were measured on (bench.py quotes them for no others)
                "launch": {"chains": cfg.get("chains_per_gpu"), "steps": cfg.get("transitions_per_step"), "thin": thin,
                           "mode": cfg.get("mode"), "layout": cfg.get("kept_rows_layout", "components")},
                "source": f"profiles/{tag}_{wl}_summary.md (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes)"}
