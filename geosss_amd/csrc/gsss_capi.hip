@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,6 +22,45 @@ static thread_local char g_err[512] = "";
 
 static thread_local LaunchInfo g_last_launch = {0, 0, 0.0};
 LaunchInfo &last_launch() { return g_last_launch; }
+
+int64_t resident_workgroups(const void *kern, size_t lds_bytes, int *per_cu_out)
+{
+    struct Entry {
+        const void *kern;
+        size_t lds;
+        int dev, per_cu, cus;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry &e : cache)
+            if (e.kern == kern && e.lds == lds_bytes && e.dev == dev) {
+                if (per_cu_out) *per_cu_out = e.per_cu;
+                return (int64_t)e.per_cu * e.cus;
+            }
+    }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    cache.push_back(Entry{kern, lds_bytes, dev, per_cu, cus});
+    if (per_cu_out) *per_cu_out = per_cu;
+    return (int64_t)per_cu * cus;
+}
+
+void slice_fallback_note(const char *why)
+{
+    if (getenv("GSSS_DEBUG_OCCUPANCY")) fprintf(stderr, "gsss: %s\n", why);
+}
 
 void set_error(const char *fmt, ...)
 {

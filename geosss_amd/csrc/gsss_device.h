@@ -74,7 +74,7 @@ struct RunBlock {
 // barrier -> lane 0: agent release, s_waitcnt, relaxed flag store; consumer: relaxed poll -> agent acquire -> s_waitcnt vmcnt(0)
 // -> barrier -> plain loads).  Slice boundaries are multiples of slice_steps in global step ids (the first slice of a launch
 // runs up to the next one), a multiple of kCoefRefresh, so a kernel that refreshes carried quantities at those steps computes
-// the same bits sliced or not.  A wait that does not end (cannot happen) gives up after ~3 s and flags the chains.
+// the same bits sliced or not.  A wait that does not end (cannot happen) gives up after ~4 s per predecessor and flags the chains.
 // ------------------------------------------------------------------------------------------
 struct SliceSched {
     // (no state of its own: everything follows from the launch arguments, so that nothing of it stays in registers while a
@@ -113,10 +113,16 @@ struct SliceSched {
         if (slice > 0) {
             __syncthreads();
             if (threadIdx.x == 0) {
-                uint32_t spins = 0, ok = 1;
+                // Slice k of a chunk can start when its k predecessors have run one after the other, so the give-up limit grows
+                // with k (~4 s per predecessor at ~1 us a poll: three orders of magnitude above a slice's own time; the host keeps a
+                // launch to <= kMaxSlices slices, so the longest legitimate wait is a few hundred slice times).  It only exists so
+                // that a lost predecessor ends in error flags instead of a hung GPU; it is not a scheduling decision.
+                uint32_t ok = 1;
+                uint64_t spins = 0;
+                const uint64_t limit = (uint64_t)(slice + 1u) << 22;
                 while (__hip_atomic_load(progress(a) + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < slice) {
                     __builtin_amdgcn_s_sleep(32);
-                    if (++spins > (1u << 22)) {
+                    if (++spins > limit) {
                         ok = 0;
                         break;
                     }
@@ -166,6 +172,25 @@ struct SlicePlan {
     int64_t grid = 0;
     int32_t slice_steps = 0;
 };
+// A chunk's slices run one after the other, each waiting for its predecessor's hand-over: a launch is cut into at most
+// kMaxSlices of them (long launches through the C ABI get longer slices: n_steps = 10^6 -> 15 680 steps per slice), so the
+// serial chain a workgroup can wait on stays short whatever the caller asks for.  A multiple of 64 (kCoefRefresh).
+constexpr int kMaxSlices = 64;
+inline int slice_length(int64_t n_steps)
+{
+    const char *env = getenv("GSSS_SLICE_STEPS");  // (read per launch: tests switch it)
+    // (measured at 10^5 chains x 1000 steps, d = 10 / 50 / 200: 64 -> 24.1 / 40.0 / 107.3 ms, 128 -> 23.8 / 39.7 / 106.1)
+    const int env_val = env ? atoi(env) : 128;
+    if (env_val <= 0) return 0;
+    int64_t steps = ((int64_t)env_val + 63) / 64 * 64;
+    const int64_t floor_steps = ((n_steps + kMaxSlices - 1) / kMaxSlices + 63) / 64 * 64;
+    if (steps < floor_steps) steps = floor_steps;
+    return steps < 0x40000000ll ? (int)steps : 0;
+}
+// hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs of the current device, cached per (kernel, LDS bytes): the query costs
+// tens of microseconds and next(sampler) loops launch once per step
+int64_t resident_workgroups(const void *kern, size_t lds_bytes, int *per_cu_out = nullptr);  // gsss_capi.hip; 0: the query failed
+void slice_fallback_note(const char *why);                                                     // GSSS_DEBUG_OCCUPANCY: say so on stderr
 // what the calling thread's last gsss_run launched (gsss_last_launch): grid 0 = a kernel that does not plan slices
 struct LaunchInfo {
     int64_t grid;
@@ -180,23 +205,17 @@ inline SlicePlan plan_slices(Kern kern, size_t lds_bytes, const RunBlock &rb, in
     p.grid = n_chunks;
     last_launch() = LaunchInfo{n_chunks, 0, 0.0};
     if (!allowed) return p;
-    const char *env = getenv("GSSS_SLICE_STEPS");  // (read per launch: tests switch it)
-    const int env_val = env ? atoi(env) : 128;  // (measured at 10^5 chains x 1000 steps, d = 10 / 50 / 200: 64 -> 24.1 / 40.0 / 107.3 ms, 128 -> 23.8 / 39.7 / 106.1)
-    const int env_steps = env_val > 0 ? ((env_val + 63) / 64) * 64 : 0;
+    const int env_steps = slice_length(rb.n_steps);
     if (env_steps <= 0 || rb.n_steps < 2 * (int64_t)env_steps) return p;
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
-        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-        (void)hipGetLastError();
-        return p;
-    }
-    const int64_t resident = (int64_t)per_cu * cus;
+    const int64_t resident = resident_workgroups(reinterpret_cast<const void *>(kern), lds_bytes);
+    if (resident < 1) return p;
     const int64_t n_slices = 2 + rb.n_steps / env_steps;
     if (n_chunks <= resident || n_chunks * n_slices >= 0x7FFFFFFFll || rb.n_chains >= 0x7FFFFFFFll) return p;
     const size_t bytes = slice_sched_bytes(n_chunks, rb.n_chains);
     void *ws = nullptr;
     if (hipMallocAsync(&ws, bytes, st) != hipSuccess || ws == nullptr) {
         (void)hipGetLastError();
+        slice_fallback_note("hipMallocAsync of the slice workspace failed: launching unsliced");
         return p;
     }
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
@@ -226,17 +245,10 @@ inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock 
     first_out = 0;
     last_launch() = LaunchInfo{n_chunks, 0, 0.0};
     if (!allowed) return p;
-    const char *env = getenv("GSSS_SLICE_STEPS");
-    const int env_val = env ? atoi(env) : 128;
-    const int env_steps = env_val > 0 ? ((env_val + 63) / 64) * 64 : 0;
+    const int env_steps = slice_length(rb.n_steps);
     if (env_steps <= 0 || rb.n_steps < 2 * (int64_t)env_steps) return p;
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
-        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-        (void)hipGetLastError();
-        return p;
-    }
-    const int64_t resident = (int64_t)per_cu * cus;
+    const int64_t resident = resident_workgroups(reinterpret_cast<const void *>(kern), lds_bytes);
+    if (resident < 1) return p;
     const int64_t rem = n_chunks % resident, first = n_chunks - rem;
     if (n_chunks <= resident || rem == 0 || 4 * rem > 3 * resident || rb.n_chains >= 0x7FFFFFFFll) return p;
     const int64_t first_len = env_steps - (int64_t)(rb.step_offset % (uint64_t)env_steps), rest = rb.n_steps - first_len;
@@ -246,6 +258,7 @@ inline SlicePlan plan_partial_round(Kern kern, size_t lds_bytes, const RunBlock 
     void *ws = nullptr;
     if (hipMallocAsync(&ws, bytes, st) != hipSuccess || ws == nullptr) {
         (void)hipGetLastError();
+        slice_fallback_note("hipMallocAsync of the slice workspace failed: launching unsliced");
         return p;
     }
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
@@ -538,7 +551,9 @@ __device__ __forceinline__ void stats_update_group(const RunBlock &a, int64_t c,
     const int r_prev = 1, r_sum = 1 + d, r_xx = 1 + 2 * d, r_dist = r_xx + T, r_hop = r_dist + 1, r_mode = r_hop + 1;
     const int r_p = r_mode + K, r_lag = r_p + 2, r_ring = r_lag + L, r_head = r_ring + L;
     const double *w = a.stats_dirs, *h = a.stats_dirs + d, *modes = a.stats_dirs + 2 * d;
-    const int64_t cnt = (int64_t)s[0];
+    // the draw count is read by the lane that writes it (lane 0 of the group, at the end of this function) and handed to the
+    // others through the group sum: no lane reads a word another lane stores
+    const int64_t cnt = (int64_t)V::reduce(g == 0 ? s[0] : 0.0);
     double p = 0.0, xh = 0.0, dot = 0.0, ph = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {

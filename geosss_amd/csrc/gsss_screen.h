@@ -669,7 +669,6 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
 {
     using V = LaneVec<D>;
     using Chain = ScreenChain<D, TP>;
-    using Coef = typename TP::Coef;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     TP tp;
     tp.stage(lds, tb);
@@ -1105,22 +1104,21 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     int32_t first = 0;
     const char *env_one = getenv("GSSS_ONE_PER_LANE");  // "0": always two chains per lane, "2": always one (tests, measurements)
     if (!(env_one && env_one[0] == '0') && screen_parks<D, TP>() && !REPLAY) {
-        int per_cu = 0, dev = 0, cus = 0;
+        int per_cu = 0;
+        int64_t resident = 0;
         if (env_one && env_one[0] == '2')
             one_per_lane = true;
-        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) == hipSuccess && per_cu >= 1 &&
-                 hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 1) {
-            const int64_t resident = (int64_t)per_cu * cus, b2 = (rb.n_chains + 2 * kBlock - 1) / (2 * kBlock);
+        else if ((resident = resident_workgroups(reinterpret_cast<const void *>(kern), lds, &per_cu)) >= 1) {
+            const int64_t b2 = (rb.n_chains + 2 * kBlock - 1) / (2 * kBlock);
             one_per_lane = 20 * b2 < 27 * resident;
             // ... and at ANY size where the LDS of the parked chains is what limits the workgroups per CU: without it more
             // wavefronts are resident, and the hardware's switching between them beats the lanes' own between two chains
             // (tools/bench_packing_shapes.py, 10^6 chains: vMF mixtures d = 10 K = 3 / 5 / 10 1.84 -> 2.35 / 1.62 -> 1.91 / 1.33 ->
             // 1.60e10 chain-steps/s, d = 8 K = 3 2.09 -> 2.58e10; equal occupancy: two per lane ahead by up to 10 %)
             int per_cu_one = 0;
-            if (!one_per_lane && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, kern, kBlock, (TP::lds_doubles() + kTabLds) * sizeof(double)) == hipSuccess)
+            if (!one_per_lane && resident_workgroups(reinterpret_cast<const void *>(kern), (TP::lds_doubles() + kTabLds) * sizeof(double), &per_cu_one) >= 1)
                 one_per_lane = per_cu_one > per_cu;
-        } else
-            (void)hipGetLastError();
+        }
     }
     if (one_per_lane) {
         per_block = kBlock;

@@ -53,8 +53,13 @@ def determine_burnin(n_samples, burnin):
     return int(burnin)
 
 
+_children_built = {}  # id(bit generator) -> [the bit generator, samplers keyed from it so far]
+
+
 def seed_to_key(seed):
-    """64-bit Philox key from what np.random.default_rng accepts as `seed` (mcmc.py:45)."""
+    """64-bit Philox key from what np.random.default_rng accepts as `seed` (mcmc.py:45).  A Generator / BitGenerator is
+    neither advanced nor otherwise changed: successive samplers built from one generator get successive children of its
+    seed sequence (the reference's samplers would share the generator and so draw different numbers too)."""
     if seed is None:
         w = np.random.SeedSequence().generate_state(2, np.uint32)
     elif isinstance(seed, (int, np.integer)):
@@ -67,14 +72,27 @@ def seed_to_key(seed):
         w = seed.generate_state(2, np.uint32)
     elif isinstance(seed, (np.random.Generator, np.random.BitGenerator)):
         # The reference shares the caller's generator (default_rng(gen) returns it, mcmc.py:45), so two samplers built from one
-        # generator draw different numbers.  Here every construction SPAWNS a child of the generator's seed sequence and keys
-        # the Philox stream from it: successive samplers get different keys, the caller's stream position is not touched
-        # (sampler.rng stays where it was).  A generator without a seed sequence (restored from a state) has nothing to spawn
-        # from: the key is drawn from the generator itself, which advances it -- as round 1 did.
+        # generator draw different numbers.  Here every construction keys the Philox stream from a further child of the
+        # generator's seed sequence: successive samplers get different keys, the caller's stream position and seed sequence
+        # are not touched.  A generator without a seed sequence (restored from a state) has nothing to derive from: the key
+        # is drawn from the generator itself, which advances it -- as round 1 did.
         bg = seed.bit_generator if isinstance(seed, np.random.Generator) else seed
         ss = getattr(bg, "seed_seq", None)
         if isinstance(ss, np.random.SeedSequence):
-            w = ss.spawn(1)[0].generate_state(2, np.uint32)
+            # a child of the generator's seed sequence WITHOUT touching the caller's object (ss.spawn would advance its
+            # n_children_spawned and so change what the caller's own later spawn() calls return): the library counts the
+            # samplers built from this bit generator itself and derives child number 2^31 + count (a fresh generator of
+            # the same seed starts at 0 again: same program, same keys)
+            entry = _children_built.get(id(bg))
+            if entry is None or entry[0] is not bg:
+                if len(_children_built) >= 1024:               # (bounded: forget the generator seen longest ago)
+                    _children_built.pop(next(iter(_children_built)))
+                entry = _children_built[id(bg)] = [bg, 0]      # (the reference keeps the id from being reused)
+            count = entry[1]
+            entry[1] = count + 1
+            child = np.random.SeedSequence(entropy=ss.entropy, spawn_key=tuple(ss.spawn_key) + (2**31 + count,),
+                                           pool_size=ss.pool_size)
+            w = child.generate_state(2, np.uint32)
         else:
             g = seed if isinstance(seed, np.random.Generator) else np.random.Generator(seed)
             w = g.integers(0, 2**32, size=2, dtype=np.uint64)
@@ -530,7 +548,7 @@ class MetropolisHastings(RejectionSphericalSliceSampler):
         # stepsize after every RWMH proposal, kept on the device per launch ([steps, chains], NaN where the step proposed
         # otherwise): 8 bytes per chain-step, so only on request -- or by default for ONE chain of the mixture sampler below
         self._record_stepsize = bool(record_stepsize)
-        self._stepsize_traces = []
+        self._trace_buf, self._trace_len = None, 0   # one [capacity, n_chains] buffer that doubles: no allocation per launch
         if not float(stepsize) > 0.0:
             raise AssertionError("stepsize must be positive")  # mcmc.py:98
         self._stepsize = torch.full((self.n_chains,), float(stepsize), dtype=torch.float64, device=self._tdev)
@@ -550,18 +568,27 @@ class MetropolisHastings(RejectionSphericalSliceSampler):
         a.n_tries_dev = None
         self._counter += n_steps
         if self._record_stepsize and self._sampler != _lib.HMC and n_steps > 0:
-            trace = torch.full((n_steps, self.n_chains), float("nan"), dtype=torch.float64, device=self._tdev)
-            a.stepsize_trace_dev = trace.data_ptr()
-            self._stepsize_traces.append(trace)
+            need = self._trace_len + n_steps
+            if self._trace_buf is None or need > self._trace_buf.shape[0]:
+                grown = torch.empty((max(need, 2 * self._trace_len, 64), self.n_chains), dtype=torch.float64, device=self._tdev)
+                if self._trace_len:
+                    grown[: self._trace_len] = self._trace_buf[: self._trace_len]
+                self._trace_buf = grown
+            rows = self._trace_buf[self._trace_len:need]
+            rows.fill_(float("nan"))
+            a.stepsize_trace_dev = rows.data_ptr()
+            self._trace_len = need
 
     def stepsize_trace(self):
         """[steps, chains] CUDA tensor: the stepsize after every recorded step that made a RWMH proposal, NaN for the others
-        (needs record_stepsize=True)."""
-        if not self._stepsize_traces:
+        (needs record_stepsize=True).  Accumulates over the sampler's lifetime, as the reference's `rwmh_stepsize_vals` list
+        does (mcmc.py:201, 228: reset() does not clear it); `clear_stepsize_trace()` drops it."""
+        if self._trace_buf is None:
             return torch.empty((0, self.n_chains), dtype=torch.float64, device=self._tdev)
-        if len(self._stepsize_traces) > 1:
-            self._stepsize_traces = [torch.cat(self._stepsize_traces)]
-        return self._stepsize_traces[0]
+        return self._trace_buf[: self._trace_len]
+
+    def clear_stepsize_trace(self):
+        self._trace_buf, self._trace_len = None, 0
 
     @property
     def stepsize(self):

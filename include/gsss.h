@@ -245,7 +245,9 @@ int gsss_run(const gsss_target *t, const gsss_run_args *args, void *stream);
 /* What the calling thread's last gsss_run launched, for logs and benches: the grid of the sampler kernel and the slice length if
  * the launch was SLICED (kernels whose chunks of chains do not fit the chip at once run one workgroup per (chunk, slice of steps)
  * and hand the chunk's state from slice to slice through HBM: (16 d + 32) / slice_steps more bytes per chain-step than an unsliced
- * launch; same results bit for bit; GSSS_SLICE_STEPS in the environment sets the length, 0 turns it off).  slice_steps 0:
+ * launch; same results bit for bit; GSSS_SLICE_STEPS in the environment sets the length, 0 turns it off; a launch is cut into at
+ * most 64 slices per chunk -- long launches get longer slices, n_steps = 10^6 -> 15 680 steps --, so the chain of hand-overs a
+ * workgroup may wait on stays short for any n_steps < 2^31).  slice_steps 0:
  * unsliced; grid 0: a kernel family that never slices.  sliced_fraction: the share of the chains that ran sliced (the lane
  * kernels slice only a small last round of workgroups).  Any pointer may be NULL.  There is nothing in the reference this
  * replaces. */

@@ -142,6 +142,8 @@ def test_seed_argument_handling():
     before = g.bit_generator.state
     k1, k2 = seed_to_key(g), seed_to_key(g)
     assert k1 != k2 and g.bit_generator.state == before
+    assert g.bit_generator.seed_seq.n_children_spawned == 0               # the caller's seed sequence is not spawned from either
+    assert [c.spawn_key for c in g.bit_generator.seed_seq.spawn(2)] == [(0,), (1,)]  # ... so the caller's own children are what they would have been
     h = np.random.default_rng(5)
     assert (seed_to_key(h), seed_to_key(h)) == (k1, k2)                  # reproducible: same generator history, same keys
     assert seed_to_key(h.bit_generator) not in (k1, k2)                  # a BitGenerator spawns from the same sequence

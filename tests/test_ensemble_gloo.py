@@ -37,7 +37,7 @@ def _worker(rank, world, port, n_total, d, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 1000), (2, 1001), (3, 64)])
+@pytest.mark.parametrize("world,n_total", [(2, 1000), (2, 1001), (3, 64), (8, 32768), (8, 32771)])  # (8: the node of BASELINE cfg5)
 def test_gather_and_bounds(tmp_path, world, n_total):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_total, 3, str(tmp_path)), nprocs=world, join=True)

@@ -985,3 +985,36 @@ def test_one_chain_per_lane_equals_two(gs, name, monkeypatch):
     assert out["big"][3] >= (n_big + 511) // 512 and out["big"][3] < (n_big + 255) // 256
     for i in range(3):
         assert torch.equal(out["big"][i], out["small"][i]), i
+
+
+def test_long_launch_gets_longer_slices(gs, monkeypatch):
+    """A launch is cut into at most 64 slices per chunk (slice_length, gsss_device.h): a C-ABI caller that asks for 20 000 steps
+    in ONE gsss_run gets 320-step slices instead of 157 of 128 steps waiting on each other in a row -- and, as for any slice
+    length, the same bits as the unsliced launch.  (The Python classes cap a launch at 4096 steps; the cap is lifted here.)"""
+    import ctypes as C
+    import torch
+    from geosss_amd import mcmc
+    monkeypatch.setattr(mcmc, "_MAX_STEPS_PER_LAUNCH", 1 << 30)
+    z = golden("traj_curve_d10_kappa800.npz")
+    pdf = product_target(z)
+    n, n_steps = 52_000, 20_000                                      # 813 chunks of 64 chains: more than the chip holds at once
+    x0 = gs.sample_sphere_device(9, n, seed=59).T
+    out, slice_steps = {}, {}
+    for label, env in (("whole", "0"), ("default", None)):
+        if env is None:
+            monkeypatch.delenv("GSSS_SLICE_STEPS", raising=False)
+        else:
+            monkeypatch.setenv("GSSS_SLICE_STEPS", env)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=12, mode="fast", placement="packed", step_offset=5)
+        kept = s.advance(n_steps, thin=5000)
+        steps = C.c_int32(0)
+        s._lib.gsss_last_launch(None, C.byref(steps), None)
+        slice_steps[label] = int(steps.value)
+        out[label] = (s.state_device.clone(), kept.clone(), s._n_tries.clone(), s._n_reject.clone(), s._err.clone())
+    assert slice_steps["whole"] == 0
+    if slice_steps["default"] == 0:
+        pytest.skip("this box holds all chunks at once: nothing was sliced")
+    assert slice_steps["default"] == 320                              # ceil(20 000 / 64) rounded up to a multiple of 64
+    for i in range(5):
+        assert torch.equal(out["whole"][i], out["default"][i]), i
+    assert int((out["whole"][4] != 0).sum()) == 0
