@@ -276,6 +276,57 @@ def ess_per_sec(gs, sampler, pdf, steps_per_sec_total, n_steps=4000, thin=4, lag
     return out
 
 
+def ess_between_chains_doubling(gs, torch, sampler, pdf, workload, steps_per_sec_total, budget_s=2.0, sub_chains=16384):
+    """Slowly mixing targets (the curve-vMF family: the chain creeps along the curve, tau of the first coordinate is 10^4 .. 10^6
+    steps): no window of a bench-sized launch holds the autocorrelation, and a between-chain estimate is only as good as
+    its window is long (n >> tau) and its chains are stationary (burn-in >> tau).  So: doubling windows on a sub-ensemble of the
+    timed chains (every window is the burn-in of the next), within a time budget; the last window's tau with its length over
+    tau, `converged` when that ratio is >= 20 and tau moved < 10 % against the window before -- otherwise tau is a LOWER bound,
+    and the figure of the run-out measurement (tools/ess_convergence.py, profiles/r04_ess_convergence.json) is quoted beside it."""
+    from geosss_amd import diagnostics as dg
+    m = min(sub_chains, sampler.n_chains)
+    sub = gs.ShrinkageSphericalSliceSampler(pdf, sampler.state_device[:, :m].T.contiguous(), seed=3521, chain_offset=sampler.chain_offset,
+                                            step_offset=sampler._step, placement="packed")
+    steps, used, prev, hist = 8192, 0.0, None, []
+    rate = None
+    while True:
+        if rate is not None and used + steps / rate > budget_s:
+            break
+        thin = max(1, steps // 512)
+        sub.enable_stats(lags=4, second_moment=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sub.advance(steps, thin=thin, keep=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        used += dt
+        rate = steps / dt
+        r = sub.stats()
+        bc = dg.ess_between_chains(r["proj_mean"], r["n"], r["proj_var"])
+        tau = bc["tau"] * thin
+        hist.append({"window_steps": steps, "tau_steps": tau})
+        change = abs(tau / prev - 1.0) if prev else None
+        prev = tau
+        steps *= 2
+    last = hist[-1]
+    ratio = last["window_steps"] / last["tau_steps"]
+    converged = bool(ratio >= 20.0 and change is not None and change < 0.10)
+    out = {"tau_steps": last["tau_steps"], "tau_is": "estimate" if converged else "lower bound (window / tau too small or still moving)",
+           "window_steps": last["window_steps"], "window_over_tau": ratio, "change_vs_previous_window": change, "converged": converged,
+           "ess_per_step": 1.0 / last["tau_steps"], "ess_per_sec": steps_per_sec_total / last["tau_steps"],
+           "ess_is": "estimate" if converged else "upper bound", "chains": m, "rel_se": bc["rel_se"], "windows": hist,
+           "estimator": "tau = n Var_chains(chain mean) / Var(x) on doubling windows of a sub-ensemble of the timed chains (every window "
+                        "is the next one's burn-in); no lag window"}
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r04_ess_convergence.json")))[workload]
+        out["run_out"] = dict(ref, ess_per_step=1.0 / ref["tau_steps"], ess_per_sec=steps_per_sec_total / ref["tau_steps"],
+                              source="profiles/r04_ess_convergence.json (tools/ess_convergence.py: the same estimator run until the "
+                                     "window is >= 16 tau; a property of target and sampler, not of the kernel build)")
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
 def measured_traffic(workload, n, S, thin, mode, layout="chains"):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); only quoted when this
@@ -410,6 +461,11 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="
     # (the curve targets mix over a thousand steps and more: thin 128, so that the 64 lags span 8192 steps)
     ess_steps, ess_thin = (32768, 128) if name.startswith("curve") else ((2000, 8) if name.startswith("bingham") else (2000, 4))
     ess_out = ess_per_sec(gs, s, pdf, value, n_steps=ess_steps, thin=ess_thin) if ess and rng != "numpy" else None
+    if ess_out is not None and name.startswith("curve"):
+        # (the one-window figure above took the timed launches as burn-in: ~10^4 steps against tau = 10^4 .. 10^6 -- not stationary,
+        # not long enough; it stays in the line as `one_window`, the doubling windows replace it)
+        ess_out["between_chains_one_window"] = ess_out.pop("between_chains")
+        ess_out["between_chains"] = ess_between_chains_doubling(gs, torch, s, pdf, name, value)
     return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}"
                         + (", rng=numpy (one PCG64 generator per chain), packed" if rng == "numpy" else ""),
             "stream": STREAM_NUMPY if rng == "numpy" else stream_description(d), "slice_steps": slice_steps,

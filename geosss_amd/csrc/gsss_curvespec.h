@@ -133,7 +133,16 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     constexpr int N = V::N;
     constexpr int kRing = 4 * L;
     constexpr int kScratch = curvespec_scratch_doubles<L, NK>();
-    constexpr bool kRecur = L >= 16;  // a_i.x by recurrence between refreshes
+    // a_i.x by recurrence between refreshes (every kCoefRefresh global steps and at the first step of a launch or slice).  Round 4:
+    // for every group size -- rounds 2-3 formed it from x at every step for L = 4 / 8 (10 further dots and group sums a step: 80 of
+    // the 1878 vector instructions of a wavefront-step at d = 10, 200 of 2736 at d = 50) so that a run split over launches gave
+    // the same bits; now a split shows at the 1e-13 level, as it always has for L = 16 and the cooperative kernels of the other
+    // targets (tests/test_hip_parity.py::test_cooperative_fast_resume), never in an integer output; sliced launches cut at
+    // multiples of the refresh period and stay bit-equal to unsliced ones.
+#ifndef GSSS_CS_RECUR_SMALL
+#define GSSS_CS_RECUR_SMALL 1
+#endif
+    constexpr bool kRecur = L >= 16 || GSSS_CS_RECUR_SMALL;
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
     const int d = tb.d, k = tb.k;
@@ -527,9 +536,15 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
 #pragma unroll
                 for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
             }
-            if (kRecur && g == 0) {
+            if (kRecur) {  // a . x' = c a.x + s a.u, knot r by lane r mod L of the group
 #pragma unroll
-                for (int r = 0; r < NK; ++r) coef[2 * r] = fma(cs, coef[2 * r], sn * coef[2 * r + 1]);  // a . x' = c a.x + s a.u
+                for (int r0 = 0; r0 < NK; r0 += L) {
+                    const int r = r0 + g;
+                    if (r < NK) {
+                        const double2 cu = *reinterpret_cast<const double2 *>(coef + 2 * r);
+                        coef[2 * r] = fma(cs, cu.x, sn * cu.y);
+                    }
+                }
             }
             ++steps_done;
             if ((a.samples != nullptr || STATS) && --until_keep == 0) {
