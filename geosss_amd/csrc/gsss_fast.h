@@ -211,6 +211,9 @@ struct FastBingham {
             quu = fma(ua, u[j], quu);
             bx = fma(b[j], x[j], bx);
             bu = fma(b[j], u[j], bu);
+            // d > 10: one column at a time -- left alone the scheduler hoists the LDS reads of many columns (d of them each) and
+            // the d = 12 / 14 / 15 kernels spill 50-90 bytes per lane at two wavefronts per SIMD
+            if constexpr (D > 10) __builtin_amdgcn_sched_barrier(0);
         }
         cf.qxx = qxx;
         cf.qxu = qxu;

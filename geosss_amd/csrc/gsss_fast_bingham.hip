@@ -1,5 +1,5 @@
 // GSSS_MODE_FAST instantiations for Bingham targets.
-#include "gsss_screen.h"
+#include "gsss_fast_bingham_lane.h"
 
 namespace gsss {
 
@@ -24,6 +24,16 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
     }
     GSSS_FAST_BINGHAM_DIMS(GSSS_CASE)
 #undef GSSS_CASE
+    // d = 11 .. 16, packed ensembles on the library stream: still one lane per chain (round 4)
+    if (tb.d >= 11 && tb.d <= 16 && rb.screen != 0 && !rb.spread && rb.rng_state == nullptr && !replay) {
+        switch (tb.d) {
+#define GSSS_CASE_WIDE(D) \
+    case D: return lane_bingham_wide<D>(tb, rb, probe, st);
+            GSSS_BINGHAM_WIDE_DIMS(GSSS_CASE_WIDE)
+#undef GSSS_CASE_WIDE
+        default: break;
+        }
+    }
     // larger d: lanes cooperate on one chain (A must fit the LDS: d <= 128)
     if (tb.d > 10 && tb.d <= 128) {
         // Lanes per chain x slots per lane, measured at 10^5 chains (10^9 chain-steps/s, eigenbasis / dense A): d <= 32 four

@@ -40,6 +40,26 @@ int lane_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *
     }
 }
 
+// d = 11 .. 16 (round 4): the screened lane kernel alone, one chain per lane (screen_parks is false there), mixtures of up to
+// six components in the buckets 3 and 6.  What it does not serve -- replayed and numpy streams, one-wavefront placement, the
+// all-double variant, wider mixtures, kappa beyond the screen's reach -- stays with the cooperative kernels (the caller checks).
+template <int D>
+int lane_vmf_wide(const TargetBlock &tb, const RunBlock &rb, FastProbe *probe, hipStream_t st)
+{
+    const int ks = tb.k <= 3 ? 3 : 6;
+    if (probe) GSSS_PROBE(false, "screened_kernel<%d, ScreenVmf<%d, %d>>", D, D, ks);
+    if (ks == 3) return do_screened_run<D, ScreenVmf<D, 3>, false>(tb, rb, st);
+    return do_screened_run<D, ScreenVmf<D, 6>, false>(tb, rb, st);
+}
+inline bool lane_wide_serves(const RunBlock &rb, bool replay)
+{
+    return rb.screen != 0 && !rb.spread && rb.rng_state == nullptr && !replay;
+}
+#define GSSS_VMF_WIDE_DIMS(X) X(11) X(12) X(13) X(14) X(15) X(16)
+#define GSSS_DECLARE_WIDE(D) extern template int lane_vmf_wide<D>(const TargetBlock &, const RunBlock &, FastProbe *, hipStream_t);
+GSSS_VMF_WIDE_DIMS(GSSS_DECLARE_WIDE)
+#undef GSSS_DECLARE_WIDE
+
 #define GSSS_VMF_LANE_DIMS(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #define GSSS_DECLARE(D) extern template int lane_vmf<D>(const TargetBlock &, const RunBlock &, bool, FastProbe *, hipStream_t);
 GSSS_VMF_LANE_DIMS(GSSS_DECLARE)

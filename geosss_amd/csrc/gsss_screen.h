@@ -88,7 +88,7 @@ struct ScreenVmf : FastVmf<D, KC> {
     // 18 instead of 28 words of parked state at K = 10, three workgroups per CU instead of two (and the register budget
     // of three wavefronts per SIMD asked of the compiler: 170 -> 168)
     static constexpr int kParkSkip = KC >= 6 ? 2 * KC : 0;  // (K = 3: 36.5 against 34.8 ms with it -- four workgroups per CU fit anyway)
-    static constexpr int kMinWaves = KC >= 6 ? 3 : ((GSSS_SCREEN_REGEN_THR && D == 3 && KC <= 3) ? 5 : 1);
+    static constexpr int kMinWaves = D > 10 ? ((D <= 12 && KC <= 3) ? 3 : 2) : (KC >= 6 ? 3 : ((GSSS_SCREEN_REGEN_THR && D == 3 && KC <= 3) ? 5 : 1));
     // K >= 6 forms the 2 K coefficients again at take-up (kParkSkip), which makes a swap as dear as a pair of tries: swapping only
     // when 24 lanes want to is worth 9 % (K = 10, kappa = 500: 56.6 -> 51.7 ms per 10^9 chain-steps; 12: 52.5, 32: 59.2, 44: 71.7);
     // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
@@ -224,7 +224,7 @@ struct ScreenBingham : FastBingham<D> {
     using Base = FastBingham<D>;
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 6;
-    static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
+    static constexpr int kParkSkip = 0, kMinWaves = D > 10 ? 2 : 1, kTradeMin = 1;
     static constexpr bool kCompact = false, kRegenThr = false;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
@@ -296,7 +296,7 @@ template <int D>
 struct ScreenBinghamDiag {
     static constexpr bool kLinear = false;
     static constexpr int kCoef32Floats = 4;  // q0 = -log U, q1 = qxu, q2 = (quu - qxx) - log U | margin
-    static constexpr int kParkSkip = 0, kMinWaves = D >= 9 ? 3 : 1, kTradeMin = 1;
+    static constexpr int kParkSkip = 0, kMinWaves = D >= 14 ? 2 : (D >= 9 ? 3 : 1), kTradeMin = 1;  // (d >= 14 spills at three)
     static constexpr bool kCompact = true, kRegenThr = true;
     const double *a;  // LDS [D]: the diagonal of A
     struct Coef {
@@ -616,10 +616,13 @@ struct ScreenChain {
     static constexpr int kWords = kWordsNoReplay + 1 + (kRegenThr ? 1 : 0);  // replay: + the cursor (+ the threshold uniform)
 };
 
+// d > 10 (round 4: the lane kernels of d = 11 .. 16): one chain per lane, nothing parked -- a second chain's 2 d + ... words
+// would hold the kernel to two workgroups per CU, and the registers (x and u alone are 4 d) to two or three wavefronts per
+// SIMD anyway: the hardware's switching between wavefronts does what the lanes' own between two chains does below d = 11.
 template <int D, class TP>
 __host__ __device__ constexpr bool screen_parks()
 {
-    return (size_t)ScreenChain<D, TP>::kWords * kBlock * sizeof(double) <= 78 * 1024;  // two workgroups per CU (160 KB)
+    return D <= 10 && (size_t)ScreenChain<D, TP>::kWords * kBlock * sizeof(double) <= 78 * 1024;  // two workgroups per CU (160 KB)
 }
 template <int D, class TP, bool REPLAY>
 __host__ __device__ constexpr size_t screen_lds_doubles()
@@ -805,6 +808,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         }
         cur.thr = u_thr;  // the uniform; the double-precision threshold is formed only if a try stays undecided
         const bool finite = tp.setup32(cur.x, cur.u, u_thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
+        // verification (GSSS_VARIANT_FAST_VERIFY): an infinite margin leaves EVERY try undecided -- each is then decided in double
+        // precision by decide(), and the run must reproduce the screened one bit for bit
+        if (a.screen == 2) cur.q[TP::kCoef32Floats - 1] = INFINITY;
         if (shrink) {
             cur.hi = kTwoPi * u_th0;
             cur.lo = cur.hi - kTwoPi;
@@ -959,7 +965,10 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         // the chain taken up tries next -- or may, if its undecided try is decided a rejection: its unparked coefficients
         // are formed again (a chain that waits for set-up or for its move gets new ones there / needs none)
         if (Chain::kSkip > 0 && (cur.status == kReady || is_decide(cur.status))) tp.refill(cur.x, cur.u, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
-        if constexpr (Chain::kCompact) tp.retail(reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));  // the margin
+        if constexpr (Chain::kCompact) {
+            tp.retail(reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));  // the margin
+            if (a.screen == 2) cur.q[TP::kCoef32Floats - 1] = INFINITY;
+        }
     };
 
     // A slice's state, counters and flags go to the chunk's next slice: written through (SliceSched::hand_over), so that

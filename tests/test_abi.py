@@ -214,3 +214,17 @@ def test_group_kernels_do_not_spill():
                 assert r["scratch"] == 0, (name, r)
                 assert r["occupancy"] >= waves, (name, r)
     assert seen == len(want), sorted(ru)
+
+
+def test_wide_lane_kernels_do_not_spill():
+    """The one-chain-per-lane screened kernels of d = 11 .. 16 (round 4) hold 4 d registers of state per lane: built for two or
+    three wavefronts per SIMD without scratch (a spilling lane kernel is what rounds 2-3 measured 1.1-4 x slower)."""
+    from geosss_amd import build
+    seen = 0
+    for src, dims in (("gsss_fast_vmf_d12.hip", (12,)), ("gsss_fast_vmf_d16.hip", (16,)), ("gsss_fast_bingham_wide_a.hip", (11, 12, 13)),
+                      ("gsss_fast_bingham_wide_b.hip", (14, 15, 16))):
+        for name, r in build.resource_usage(src).items():
+            if "screened_kernel" in name and "Lb0ELb0E" in name:                  # <.., replay = false, stats = false>
+                seen += 1
+                assert r["scratch"] == 0 and r["occupancy"] >= 2, (name, r)
+    assert seen == 2 * 2 + 2 * 6

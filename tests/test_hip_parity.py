@@ -305,7 +305,9 @@ def test_layout_round_trip(gs):
     assert torch.equal(o, s.permute(2, 0, 1).contiguous())
 
 
-SYNTH = [("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
+SYNTH = [("vmf", 11, 6), ("vmf", 13, 4), ("vmf", 14, 2), ("vmf", 12, 7), ("bingham", 11, 0), ("bingham", 14, 0), ("bingham", 16, 0), ("bingham_diag", 12, 0),
+         ("bingham_diag", 15, 0), ("bingham_diag", 16, 0),
+         ("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
          ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7),
          ("curve", 9, 10), ("curve", 15, 10), ("curve", 18, 10), ("curve", 21, 10), ("bingham", 7, 0), ("bingham", 9, 0),
          ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10),
@@ -332,9 +334,10 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k, monkeypatch):
         w = rng.uniform(0.5, 2.0, k)
         pdf = gs.MixtureModel([gs.VonMisesFisher(m) for m in mu], w)
         tgt = oracle.Target.vmf_mixture(mu, w)
-    elif kind == "bingham":
-        pdf = gs.random_bingham(d=d, vmax=25.0, vmin=-2.0, eigensystem=False, seed=d)
+    elif kind.startswith("bingham"):
+        pdf = gs.random_bingham(d=d, vmax=25.0, vmin=-2.0, eigensystem=kind == "bingham_diag", seed=d)
         tgt = oracle.Target.bingham(pdf.A)
+        kind = "bingham"
     else:
         knots = gs.brownian_curve(k, d, 0.5, seed=d)
         pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 300.0)
@@ -353,6 +356,8 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k, monkeypatch):
             assert s.mode == "fast"
         if kind == "curve" and 4 <= d <= 256 and placement == "packed":      # the group-speculative kernel from d = 4 on
             assert _packed_kernel(s).startswith("curvespec_kernel")
+        if kind != "curve" and d <= 16 and placement == "packed" and (kind == "bingham" or k <= (6 if d > 10 else 16)):
+            assert _packed_kernel(s).startswith("screened_kernel")            # lane kernels up to d = 16 (round 4: 11 .. 16)
         kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
         assert np.all(s.errors == 0)
         assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
@@ -735,7 +740,20 @@ def test_cooperative_fast_resume(gs, name):
     assert np.array_equal(a.n_tries_per_chain, ref.n_tries_per_chain)
 
 
-SCREEN_CASES = [("vmfmix_readme", 200_000, 60), ("vmfmix_k10_kappa500", 100_000, 40), ("vmfmix_d10_k5_kappa100", 50_000, 40),
+def _wide_target(gs, name):
+    """Targets of the d = 11 .. 16 lane kernels (no reference fixture at these shapes): wide:<kind>:<d>[:<k>]"""
+    _, kind, d, *rest = name.split(":")
+    d = int(d)
+    if kind == "vmf":
+        k = int(rest[0])
+        mu = 60.0 * gs.sample_sphere(d - 1, k, seed=100 + d)
+        return gs.MixtureModel([gs.VonMisesFisher(m) for m in mu], np.linspace(1.0, 2.0, k)), d
+    return gs.random_bingham(d=d, vmax=40.0, vmin=0.0, eigensystem=kind == "bingham_diag", seed=200 + d), d
+
+
+SCREEN_CASES = [("wide:vmf:12:3", 60_000, 40), ("wide:vmf:16:6", 40_000, 30), ("wide:bingham_diag:12", 60_000, 40), ("wide:bingham_diag:16", 40_000, 30),
+                ("wide:bingham:11", 40_000, 30), ("wide:bingham:16", 30_000, 30),
+                ("vmfmix_readme", 200_000, 60), ("vmfmix_k10_kappa500", 100_000, 40), ("vmfmix_d10_k5_kappa100", 50_000, 40),
                 ("vmfmix_d4_k4_weighted", 50_000, 40), ("bingham_d10_vmax30", 100_000, 60), ("bingham_d5_dense", 100_000, 60),
                 ("binghamfisher_d5", 100_000, 60), ("binghamfisher_d6", 50_000, 40), ("curve_d3_kappa300", 50_000, 40),
                 ("curve_d10_kappa800", 50_000, 40), ("curve_d10_kappa500", 50_000, 40), ("curve_d24_kappa800", 20_000, 30)]
@@ -747,9 +765,13 @@ def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
     """The single-precision screen only ever takes decisions its error margin guarantees, everything else is
     decided and computed in double precision: the screened kernel and the all-double kernel give the SAME chains
     -- states bit for bit, tries and rejections exactly -- over ~10^8 proposals."""
-    z = golden(f"traj_{name}.npz")
-    pdf = product_target(z)
-    d = len(z["x0"])
+    wide = name.startswith("wide:")
+    if wide:
+        pdf, d = _wide_target(gs, name)
+    else:
+        z = golden(f"traj_{name}.npz")
+        pdf = product_target(z)
+        d = len(z["x0"])
     x0 = gs.sample_sphere_device(d - 1, n_chains, seed=77).T
     cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
     if sampler == "reject":
@@ -758,10 +780,12 @@ def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
     out = {}
     probe = cls(pdf, x0[:1], seed=5, mode="fast", placement="packed")
     spec = probe._lib.gsss_kernel_name(probe._target_dev.handle, 1, 0, 1).decode().startswith("curvespec_kernel")
-    for screen in (True, False, "verify") if spec else (True, False):
+    # "verify": the default kernel with an infinite margin -- every try decided in double precision by the kernel's own
+    # arithmetic -- must give the screened run's bits (round 4: the lane kernels too, not only the group kernels)
+    for screen in (True, False, "verify"):
         s = cls(pdf, x0, seed=5, mode="fast", placement="packed", screen=screen)
         name_k = s._lib.gsss_kernel_name(s._target_dev.handle, 1, {True: 0, False: 100, "verify": 101}[screen], 1).decode()
-        want_k = "fast_kernel" if screen is False else ("curvespec_kernel" if spec else "screened_kernel")
+        want_k = ("coopfast_kernel" if wide else "fast_kernel") if screen is False else ("curvespec_kernel" if spec else "screened_kernel")
         assert name_k.startswith(want_k), name_k
         s.advance(n_steps // 2)
         s.advance(n_steps - n_steps // 2)          # the split exercises the per-launch state hand-over
@@ -770,15 +794,15 @@ def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
     import torch
     assert torch.equal(out[True][1], out[False][1])
     assert torch.equal(out[True][2], out[False][2])
-    if spec:
-        # The group-speculative curve kernel (d >= 4) arranges its sums differently from the all-double lane kernel: same
-        # decisions (integer outputs above), states to rounding -- and bit for bit against ITSELF with the screen's verdicts
-        # ignored (every try decided in double precision by the same arithmetic).
+    if spec or wide:
+        # The group-speculative curve kernel (d >= 4) arranges its sums differently from the all-double lane kernel, and the
+        # all-double kernel of d = 11 .. 16 is the cooperative one (four lanes per chain): same decisions (integer outputs
+        # above), states to rounding.
         assert float((out[True][0] - out[False][0]).abs().max().item()) < 1e-11
-        for i in range(3):
-            assert torch.equal(out[True][i], out["verify"][i])
     else:
         assert torch.equal(out[True][0], out[False][0])
+    for i in range(3):   # bit for bit against ITSELF with the screen's verdicts ignored
+        assert torch.equal(out[True][i], out["verify"][i])
     assert int(out[True][1].sum().item()) > 4 * n_chains * n_steps * (0.9 if sampler == "shrink" else 1.0)
 
 

@@ -21,7 +21,8 @@ def rate(pdf, d, **kw):
     return n * steps / best, name
 
 
-for d in range(3, 11):
+dims = [int(a) for a in sys.argv[1:]] or list(range(3, 17))   # (round 4: lane kernels up to d = 16; screen=False is the cooperative kernel there)
+for d in dims:
     for K in (3, 5, 10):
         modes = gs.sample_sphere(d - 1, K, seed=1234, rng="numpy")
         pdf = gs.MixtureModel([gs.VonMisesFisher(100.0 * m) for m in modes])
