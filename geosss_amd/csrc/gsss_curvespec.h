@@ -27,6 +27,8 @@
 // chains agree with the other fast kernels to rounding and with the oracle on the Philox stream in every integer output.
 // Semantics followed: geosss/mcmc.py:357-401, sphere.py:10-33, spherical_curve.py:10-32, 95-102, distributions.py:272-275.
 #pragma once
+#include <type_traits>
+
 #include "gsss_screen.h"
 
 namespace gsss {
@@ -133,14 +135,15 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     constexpr int N = V::N;
     constexpr int kRing = 4 * L;
     constexpr int kScratch = curvespec_scratch_doubles<L, NK>();
-    // a_i.x by recurrence between refreshes (every kCoefRefresh global steps and at the first step of a launch or slice).  Round 4:
-    // for every group size -- rounds 2-3 formed it from x at every step for L = 4 / 8 (10 further dots and group sums a step: 80 of
-    // the 1878 vector instructions of a wavefront-step at d = 10, 200 of 2736 at d = 50) so that a run split over launches gave
-    // the same bits; now a split shows at the 1e-13 level, as it always has for L = 16 and the cooperative kernels of the other
-    // targets (tests/test_hip_parity.py::test_cooperative_fast_resume), never in an integer output; sliced launches cut at
-    // multiples of the refresh period and stay bit-equal to unsliced ones.
+    // a_i.x by recurrence between refreshes (every kCoefRefresh global steps and at the first step of a launch or slice) for
+    // sixteen-lane groups; L = 4 / 8 form it from x at every step, so that a run split over launches gives the same bits.
+    // Round 4 measured the recurrence for them too (GSSS_CS_RECUR_SMALL=1: 10 dots and group sums less a step -- 80 of the 1878
+    // vector instructions of a wavefront-step at d = 10, 200 of 2736 at d = 50), with the knot loop compiled once per value of
+    // `refresh`: 20.63 -> 20.17 ms at d = 10, 29.01 -> 27.94 at d = 24, 37.80 -> 36.73 at d = 50 on one box
+    // (profiles/r04_ab_recurrence.log; with the condition inside one loop the compiler formed the dots anyway and selected: no
+    // gain at all).  2-4 % for giving up the bitwise equality of split runs: not adopted.
 #ifndef GSSS_CS_RECUR_SMALL
-#define GSSS_CS_RECUR_SMALL 1
+#define GSSS_CS_RECUR_SMALL 0
 #endif
     constexpr bool kRecur = L >= 16 || GSSS_CS_RECUR_SMALL;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -341,45 +344,62 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
             const double rnw = inv_norm(group_sum<L>(pw));
+            // (two copies of the loop, one per value of `refresh`: as a run-time condition inside one loop the compiler turns
+            // "if (refresh) px = fma(..)" into the fma and a select -- the dots the recurrence is there to save are formed anyway)
+            auto knot_loop = [&](auto refresh_c) {
+                constexpr bool kRefresh = decltype(refresh_c)::value;
 #pragma unroll
-            for (int r = 0; r < NK; ++r) {
-                const double *row = knots + (size_t)r * DPAD;
-                double pu = 0.0, px = 0.0;
-                if constexpr (kSlotMajor) {
+                for (int r = 0; r < NK; ++r) {
+                    const double *row = knots + (size_t)r * DPAD;
+                    double pu = 0.0, px = 0.0;
+                    if constexpr (kSlotMajor) {
 #pragma unroll
-                    for (int i = 0; i < N; i += 2) {
-                        const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
-                        pu = fma(kv.x, u[i], pu);
-                        if (refresh) px = fma(kv.x, x[i], px);
-                        pu = fma(kv.y, u[i + 1], pu);
-                        if (refresh) px = fma(kv.y, x[i + 1], px);
+                        for (int i = 0; i < N; i += 2) {
+                            const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
+                            pu = fma(kv.x, u[i], pu);
+                            if (kRefresh) px = fma(kv.x, x[i], px);
+                            pu = fma(kv.y, u[i + 1], pu);
+                            if (kRefresh) px = fma(kv.y, x[i + 1], px);
+                        }
+                    } else {
+                        // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
+                        // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
+                        // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
+#pragma unroll
+                        for (int i = 0; i < N; i += 2) {
+                            const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
+                            pu = fma(kv.x, u[i], pu);
+                            if (kRefresh) px = fma(kv.x, x[i], px);
+                            pu = fma(kv.y, u[i + 1], pu);
+                            if (kRefresh) px = fma(kv.y, x[i + 1], px);
+                        }
                     }
-                } else {
-                    // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
-                    // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
-                    // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
-#pragma unroll
-                    for (int i = 0; i < N; i += 2) {
-                        const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
-                        pu = fma(kv.x, u[i], pu);
-                        if (refresh) px = fma(kv.x, x[i], px);
-                        pu = fma(kv.y, u[i + 1], pu);
-                        if (refresh) px = fma(kv.y, x[i + 1], px);
-                    }
+                    const double au = group_sum<L>(pu) * rnw;
+                    double axr;
+                    if constexpr (kRefresh)
+                        axr = group_sum<L>(px);
+                    else
+                        axr = coef[2 * r];
+                    q[r] = (float)axr;
+                    q[NK + r] = (float)au;
+                    // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
+                    // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
+                    // the pair to one owner lane (round 2: 40 of the step's vector instructions)
+                    if constexpr (kRefresh)
+                        *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
+                    else
+                        coef[2 * r + 1] = au;
+                    // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
+                    if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
                 }
-                const double au = group_sum<L>(pu) * rnw;
-                const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
-                q[r] = (float)axr;
-                q[NK + r] = (float)au;
-                // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
-                // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
-                // the pair to one owner lane (round 2: 40 of the step's vector instructions)
+            };
+            if constexpr (!kRecur) {
+                knot_loop(std::true_type{});
+            } else {
                 if (refresh)
-                    *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
+                    knot_loop(std::true_type{});
                 else
-                    coef[2 * r + 1] = au;
-                // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
-                if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
+                    knot_loop(std::false_type{});
             }
 #pragma unroll
             for (int i = 0; i < N; i += 2) {

@@ -15,9 +15,9 @@ int launch_fast_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, Fast
         default: break;
         }
     }
-    // d = 11 .. 16, K <= 6, packed ensembles on the library stream: still one lane per chain (round 4; rounds 1-3 dropped to the
+    // d = 11 .. 16, K <= 10, packed ensembles on the library stream: still one lane per chain (round 4; rounds 1-3 dropped to the
     // four-lane cooperative kernel at d = 11: 1.3 - 2.6e10 -> ~5e9 chain-steps/s)
-    if (tb.k >= 1 && tb.k <= 6 && tb.d >= 11 && tb.d <= 16 && tb.scale <= kScreenMaxKappa && lane_wide_serves(rb, replay)) {
+    if (tb.k >= 1 && tb.k <= 10 && tb.d >= 11 && tb.d <= 16 && tb.scale <= kScreenMaxKappa && lane_wide_serves(rb, replay)) {
         switch (tb.d) {
 #define GSSS_CASE(D) \
     case D: return lane_vmf_wide<D>(tb, rb, probe, st);

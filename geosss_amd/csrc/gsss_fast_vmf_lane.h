@@ -41,15 +41,16 @@ int lane_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, FastProbe *
 }
 
 // d = 11 .. 16 (round 4): the screened lane kernel alone, one chain per lane (screen_parks is false there), mixtures of up to
-// six components in the buckets 3 and 6.  What it does not serve -- replayed and numpy streams, one-wavefront placement, the
+// ten components in the buckets 3, 6 and 10.  What it does not serve -- replayed and numpy streams, one-wavefront placement, the
 // all-double variant, wider mixtures, kappa beyond the screen's reach -- stays with the cooperative kernels (the caller checks).
 template <int D>
 int lane_vmf_wide(const TargetBlock &tb, const RunBlock &rb, FastProbe *probe, hipStream_t st)
 {
-    const int ks = tb.k <= 3 ? 3 : 6;
+    const int ks = tb.k <= 3 ? 3 : (tb.k <= 6 ? 6 : 10);
     if (probe) GSSS_PROBE(false, "screened_kernel<%d, ScreenVmf<%d, %d>>", D, D, ks);
     if (ks == 3) return do_screened_run<D, ScreenVmf<D, 3>, false>(tb, rb, st);
-    return do_screened_run<D, ScreenVmf<D, 6>, false>(tb, rb, st);
+    if (ks == 6) return do_screened_run<D, ScreenVmf<D, 6>, false>(tb, rb, st);
+    return do_screened_run<D, ScreenVmf<D, 10>, false>(tb, rb, st);
 }
 inline bool lane_wide_serves(const RunBlock &rb, bool replay)
 {

@@ -227,4 +227,4 @@ def test_wide_lane_kernels_do_not_spill():
             if "screened_kernel" in name and "Lb0ELb0E" in name:                  # <.., replay = false, stats = false>
                 seen += 1
                 assert r["scratch"] == 0 and r["occupancy"] >= 2, (name, r)
-    assert seen == 2 * 2 + 2 * 6
+    assert seen == 2 * 3 + 2 * 6
