@@ -493,6 +493,9 @@ def main(argv=None):
     ap.add_argument("--layout", default="auto", choices=["auto", "chains", "components"],
                     help="retained rows: (chains, draws, dims) as the reference returns them, the kernels' [row][d][chain], or "
                          "(auto) whichever moves fewer bytes for the kernel family, see pick_layout")
+    ap.add_argument("--rng", default="philox", choices=["philox", "numpy"],
+                    help="numpy: the workload on numpy's own stream (one PCG64 generator per chain, packed) -- what configs[] times "
+                         "as <workload>__numpy_stream; for profiling that entry on its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
@@ -544,8 +547,10 @@ def main(argv=None):
     n = args.chains
     chain_offset = rank * n
     x0 = gs.sample_sphere_device(d - 1, n, seed=0, chain_offset=chain_offset)  # [d, n] on device
+    kw_rng = dict(rng="numpy", placement="packed") if args.rng == "numpy" else {}
     sampler = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=3521, chain_offset=chain_offset, mode=args.mode,
-                                                variant=args.variant)
+                                                variant=args.variant, **kw_rng)
+    wl_key = args.workload + ("__numpy_stream" if args.rng == "numpy" else "")
     S = args.inner
     thin = min(args.thin, S) if args.thin > 0 else S
     layout = pick_layout(args.layout, gs._lib.load().gsss_kernel_name(
@@ -614,15 +619,15 @@ def main(argv=None):
         slice_steps, sliced_frac = last_slice_steps(gs)
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
-        traffic, traffic_src = measured_traffic(args.workload, n, S, thin, sampler.mode, layout)
+        traffic, traffic_src = measured_traffic(wl_key, n, S, thin, sampler.mode, layout)
         out = {
             "metric": "mcmc_chain_steps_per_sec", "value": value, "unit": "chain-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: shrinkage slice sampler, {n} chains/GPU x {S} transitions per "
                                    "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
-                       "stream": stream_description(d),
-                       "target": args.workload, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
+                       "stream": STREAM_NUMPY if args.rng == "numpy" else stream_description(d),
+                       "target": wl_key, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
                        "sliced_fraction": round(sliced_frac, 4),
                        "kept_rows_layout": layout,
                        "csrc_sha256": source_digest(),
@@ -636,9 +641,9 @@ def main(argv=None):
                                      note="chain state lives in registers/LDS for the whole launch, so HBM sees only the "
                                           "state load/store, counters and the thinned sample; the kernel is bound by vector "
                                           "issue (see roofline_valu and DESIGN.md)"),
-            "roofline_valu": roofline_valu(args.workload, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms, layout),
+            "roofline_valu": roofline_valu(wl_key, d, tries / total_steps, n, S, thin, sampler.mode, kern_ms, layout),
         }
-        if world == 1 and not args.no_ess:
+        if world == 1 and not args.no_ess and args.rng != "numpy":
             out["ess"] = ess_per_sec(gs, sampler, pdf, value)
         if world == 1 and not args.no_configs and args.workload == "vmfmix_readme":
             del sampler, kept

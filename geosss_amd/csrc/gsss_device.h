@@ -47,6 +47,8 @@ struct RunBlock {
     int32_t spread;     // lane layouts: one chain per WAVEFRONT (small ensembles: no divergence between chains)
     int32_t one_per_lane;  // the lane kernels that park a second chain per lane: leave it out (mid-size ensembles: twice the
                            // workgroups while they all fit the chip at once; set by do_screened_run)
+    int32_t stage_rows;    // lane kernels, one chain per lane, chain-major retained rows of 8 d bytes that are not whole 32-byte
+                           // sectors: a lane holds rows back in LDS until their run ends on a sector boundary (gsss_screen.h)
     int32_t screen;     // fast mode: tries are screened in single precision where the target's kernel is built for it
                         // (2: verification -- the screen's verdicts are ignored by the kernels that can, see gsss.h)
     double *stats;             // NULL or [gsss_stats_rows][n_chains] running statistics of the retained series

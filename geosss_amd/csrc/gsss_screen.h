@@ -677,6 +677,14 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     tp.stage(lds, tb);
     const fm::Tables tab = stage_tables(lds + TP::lds_doubles());
     unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles() + kTabLds) + threadIdx.x;
+    // Retained rows in the reference's (chains, draws, dims) order are 8 D bytes at an 8 D byte stride: for D not a multiple of
+    // four a row ends inside a 32-byte sector, and rows that leave one at a time (a chain keeps a row every `thin` steps,
+    // milliseconds apart) are written as partial sectors -- 1.39 x the bytes at D = 10.  With one chain per lane the LDS that
+    // would park second chains is free: a lane holds a row back (at most kStageP - 1 of them) until the run of rows ends on
+    // a sector boundary and stores the run at once (a.stage_rows, set by do_screened_run; same bytes in the same places).
+    constexpr int kStageP = (D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+    double *stage = reinterpret_cast<double *>(park);  // [kStageP - 1][D][kBlock] doubles (nothing is parked in that mode)
+    int32_t n_staged = 0;
     __syncthreads();
 
     const int32_t n = (int32_t)a.n_chains;
@@ -868,6 +876,18 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         }
     };
 
+    // the rows held back in LDS go out in front of the row that starts at `p_next` (rows of one chain are contiguous)
+    auto unstage = [&](double *p_next) {
+#pragma unroll
+        for (int b = 0; b < kStageP - 1; ++b) {
+            if (b < n_staged) {
+                double *q = p_next - (size_t)(n_staged - b) * D;
+#pragma unroll
+                for (int j = 0; j < D; ++j) q[j] = stage[(size_t)(b * D + j) * kBlock];
+            }
+        }
+        n_staged = 0;
+    };
     // the double-precision part of a stopped try: decide it if the screen could not, then move (mcmc.py:396-399)
     auto finalise = [&]() {
         const double theta = cur.status >= kFinalAccept + kFinalInHi ? cur.hi : cur.lo;
@@ -904,8 +924,22 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
             }
             if (keep) {
                 if (a.samples != nullptr) {
+                    if (kStageP > 1 && a.stage_rows) {
+                        double *p = &a.samples[sample_index(a, cur.row, 0, D, chain_id())];  // chain-major: the row is contiguous
+                        const bool ends_on_sector = (reinterpret_cast<uintptr_t>(p + D) & 31u) == 0u;
+                        if (!ends_on_sector && n_staged < kStageP - 1) {
 #pragma unroll
-                    for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                            for (int j = 0; j < D; ++j) stage[(size_t)(n_staged * D + j) * kBlock] = cur.x[j];
+                            ++n_staged;
+                        } else {
+                            unstage(p);
+#pragma unroll
+                            for (int j = 0; j < D; ++j) p[j] = cur.x[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
+                    }
                 }
                 if constexpr (STATS) stats_update<D>(a, chain_id(), cur.x);
                 ++cur.row;
@@ -987,6 +1021,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     auto flush = [&]() {
         const int32_t c = chain_id();
         if (c >= n) return;
+        if (kStageP > 1 && n_staged > 0) unstage(&a.samples[sample_index(a, cur.row, 0, D, c)]);  // (the chain's next row starts there)
 #pragma unroll
         for (int j = 0; j < D; ++j) put_out(&a.state[(size_t)j * n + c], cur.x[j]);
         if (a.n_reject) put_out(&a.n_reject[c], a.n_reject[c] + ((int64_t)cur.n_try - (cur.steps_done - s_begin)));
@@ -1092,9 +1127,12 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     if constexpr (!REPLAY) {  // running statistics: a build of its own (the plain kernel carries none of it)
         if (rb.stats != nullptr) kern = screened_kernel<D, TP, false, true>;
     }
-    if (lds > 48 * 1024) {
+    // (the most either packing asks for: two chains per lane with the second one parked, or one per lane with rows held back)
+    const size_t lds_most = lds > (TP::lds_doubles() + kTabLds + (size_t)3 * D * kBlock) * sizeof(double)
+                                ? lds : (TP::lds_doubles() + kTabLds + (size_t)3 * D * kBlock) * sizeof(double);
+    if (lds_most > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_most);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GSSS_E_HIP;
@@ -1129,15 +1167,28 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
                 one_per_lane = per_cu_one > per_cu;
         }
     }
+    bool stage_rows = false;
     if (one_per_lane) {
         per_block = kBlock;
         lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
+        // chain-major retained rows that are not whole sectors are held back in that LDS until their run is (screened_kernel)
+        constexpr int kStageP = (D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+        const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
+        if (kStageP > 1 && rb.samples != nullptr && rb.keep_rows > 0 && !(env_stage && env_stage[0] == '0')) {
+            // ... unless that LDS would cost a resident workgroup (bytes at 0.3 % of the HBM peak are not worth a wavefront)
+            const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
+            if (resident_workgroups(reinterpret_cast<const void *>(kern), lds_staged) >= resident_workgroups(reinterpret_cast<const void *>(kern), lds)) {
+                stage_rows = true;
+                lds = lds_staged;
+            }
+        }
     }
     const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;
     // a small last round of workgroups is cut into step slices (plan_partial_round, gsss_device.h)
     plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>(), st, first);
     RunBlock rbl = rb;
     rbl.one_per_lane = one_per_lane ? 1 : 0;
+    rbl.stage_rows = stage_rows ? 1 : 0;
     rbl.sched = plan.ws;
     rbl.slice_steps = plan.slice_steps;
     rbl.sched_first = first;

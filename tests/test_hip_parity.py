@@ -1042,3 +1042,38 @@ def test_long_launch_gets_longer_slices(gs, monkeypatch):
     for i in range(5):
         assert torch.equal(out["whole"][i], out["default"][i]), i
     assert int((out["whole"][4] != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["vmfmix_readme", "bingham_d10_vmax30", "bingham_d5_dense", "vmfmix_d10_k5_kappa100", "vmfmix_d4_k4_weighted"])
+def test_rows_held_back_in_lds_land_where_they_belong(gs, name, monkeypatch):
+    """One chain per lane, (chains, draws, dims) output: rows of 8 d bytes that do not end on a 32-byte sector are held back in LDS
+    until their run does (screened_kernel, RunBlock::stage_rows) -- fewer partial sectors, the SAME array: with the staging
+    switched off (GSSS_STAGE_ROWS=0) every retained row of every chain is bit-identical, for odd and even row offsets (sample()
+    starts at row 1), thinning, runs of rows split over launches (the Python classes cap a launch at 4096 steps) and chains that
+    stop early (max_tries)."""
+    import torch
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    n = 30_000                                               # one chain per lane at this size
+    x0 = gs.sample_sphere_device(d - 1, n, seed=61).T
+    out = {}
+    for label, env in (("staged", None), ("plain", "0")):
+        if env is None:
+            monkeypatch.delenv("GSSS_STAGE_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("GSSS_STAGE_ROWS", env)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=14, mode="fast", placement="packed")
+        assert _packed_kernel(s).startswith("screened_kernel")
+        a = s.sample(23, burnin=3, thin=7, as_tensor=True)                # rows 1 .. 22 of a 23-row run, one launch
+        b = s.sample(12, thin=500, as_tensor=True)                        # 5500 steps: two launches, 8 + 3 rows
+        buf = torch.zeros((n, 9, d), dtype=torch.float64, device="cuda")  # an odd run length: chains start on either sector phase
+        s.advance(8 * 3, thin=3, out=buf, chain_major=True, row0=1)
+        t = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=14, mode="fast", placement="packed", max_tries=14)
+        c = torch.zeros((n, 40, d), dtype=torch.float64, device="cuda")
+        t.advance(40, thin=1, out=c, chain_major=True)                    # some chains stop early: their held-back rows still go out
+        out[label] = (a.clone(), b.clone(), buf.clone(), c.clone(), t._err.clone(), s.state_device.clone())
+    for i in range(6):
+        assert torch.equal(out["staged"][i], out["plain"][i]), i
+    assert 0 < int((out["plain"][4] != 0).sum()) < n
+    assert float(out["staged"][2][:, 0].abs().max()) == 0.0 and float(out["staged"][2][:, 1:].abs().min()) > 0.0  # row 0 untouched, rows 1 .. 8 written
