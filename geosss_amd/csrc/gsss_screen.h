@@ -94,6 +94,7 @@ struct ScreenVmf : FastVmf<D, KC> {
     // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
     static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
     static constexpr bool kCompact = false;
+    static constexpr bool kStageRows = KC <= 6;  // rows held back in LDS (screened_kernel): the wide mixtures have no register to spare
     // S^2, K <= 3 (the README target, BASELINE cfg2): the threshold uniform is not parked -- an undecided try draws it again
     // from the counter-based stream -- which makes the parked state 15 words: five workgroups per CU instead of four (the
     // kernel needs 95 registers: five wavefronts per SIMD fit)
@@ -225,7 +226,7 @@ struct ScreenBingham : FastBingham<D> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 6;
     static constexpr int kParkSkip = 0, kMinWaves = D > 10 ? 2 : 1, kTradeMin = 1;
-    static constexpr bool kCompact = false, kRegenThr = false;
+    static constexpr bool kCompact = false, kRegenThr = false, kStageRows = true;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
@@ -297,7 +298,7 @@ struct ScreenBinghamDiag {
     static constexpr bool kLinear = false;
     static constexpr int kCoef32Floats = 4;  // q0 = -log U, q1 = qxu, q2 = (quu - qxx) - log U | margin
     static constexpr int kParkSkip = 0, kMinWaves = D >= 14 ? 2 : (D >= 9 ? 3 : 1), kTradeMin = 1;  // (d >= 14 spills at three)
-    static constexpr bool kCompact = true, kRegenThr = true;
+    static constexpr bool kCompact = true, kRegenThr = true, kStageRows = true;
     const double *a;  // LDS [D]: the diagonal of A
     struct Coef {
         double qxx, qxu, quu;
@@ -504,7 +505,7 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
-    static constexpr bool kCompact = false, kRegenThr = false;
+    static constexpr bool kCompact = false, kRegenThr = false, kStageRows = false;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     Curve32<NK> c32;
@@ -682,7 +683,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     // milliseconds apart) are written as partial sectors -- 1.39 x the bytes at D = 10.  With one chain per lane the LDS that
     // would park second chains is free: a lane holds a row back (at most kStageP - 1 of them) until the run of rows ends on
     // a sector boundary and stores the run at once (a.stage_rows, set by do_screened_run; same bytes in the same places).
-    constexpr int kStageP = (D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+    // (built where second chains are parked, d <= 10: beyond, the rows' LDS would cost the one-per-lane kernels a workgroup)
+    // ... and where the target's kernel has the registers for it (TP::kStageRows: not the K >= 10 mixtures, which sit on their budget)
+    constexpr int kStageP = (!TP::kStageRows || D > 10 || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
     double *stage = reinterpret_cast<double *>(park);  // [kStageP - 1][D][kBlock] doubles (nothing is parked in that mode)
     int32_t n_staged = 0;
     __syncthreads();
@@ -1172,7 +1175,7 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
         per_block = kBlock;
         lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
         // chain-major retained rows that are not whole sectors are held back in that LDS until their run is (screened_kernel)
-        constexpr int kStageP = (D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+        constexpr int kStageP = (!TP::kStageRows || D > 10 || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
         const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
         if (kStageP > 1 && rb.samples != nullptr && rb.keep_rows > 0 && !(env_stage && env_stage[0] == '0')) {
             // ... unless that LDS would cost a resident workgroup (bytes at 0.3 % of the HBM peak are not worth a wavefront)
