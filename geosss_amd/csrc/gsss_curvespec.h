@@ -27,8 +27,6 @@
 // chains agree with the other fast kernels to rounding and with the oracle on the Philox stream in every integer output.
 // Semantics followed: geosss/mcmc.py:357-401, sphere.py:10-33, spherical_curve.py:10-32, 95-102, distributions.py:272-275.
 #pragma once
-#include <type_traits>
-
 #include "gsss_screen.h"
 
 namespace gsss {
@@ -137,15 +135,13 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
     constexpr int kScratch = curvespec_scratch_doubles<L, NK>();
     // a_i.x by recurrence between refreshes (every kCoefRefresh global steps and at the first step of a launch or slice) for
     // sixteen-lane groups; L = 4 / 8 form it from x at every step, so that a run split over launches gives the same bits.
-    // Round 4 measured the recurrence for them too (GSSS_CS_RECUR_SMALL=1: 10 dots and group sums less a step -- 80 of the 1878
-    // vector instructions of a wavefront-step at d = 10, 200 of 2736 at d = 50), with the knot loop compiled once per value of
-    // `refresh`: 20.63 -> 20.17 ms at d = 10, 29.01 -> 27.94 at d = 24, 37.80 -> 36.73 at d = 50 on one box
-    // (profiles/r04_ab_recurrence.log; with the condition inside one loop the compiler formed the dots anyway and selected: no
-    // gain at all).  2-4 % for giving up the bitwise equality of split runs: not adopted.
-#ifndef GSSS_CS_RECUR_SMALL
-#define GSSS_CS_RECUR_SMALL 0
-#endif
-    constexpr bool kRecur = L >= 16 || GSSS_CS_RECUR_SMALL;
+    // Round 4 measured the recurrence for them too (10 dots and group sums less a step: 80 of the 1878 vector instructions of a
+    // wavefront-step at d = 10, 200 of 2736 at d = 50).  With `refresh` a run-time condition inside this one loop the compiler forms
+    // the dots anyway and selects: no gain (20.79 -> 20.89 ms at d = 10).  With the loop compiled once per value of `refresh`:
+    // 20.63 -> 20.17 ms (d = 10), 29.01 -> 27.94 (d = 24), 37.80 -> 36.73 (d = 50) -- but that restructuring ALONE cost the
+    // two-wavefront builds 8-11 % (d = 50 34.83 -> 37.79 ms, d = 200 97.7 -> 108.7: another schedule of the same operations, 250
+    // instead of 254 registers, more exposed LDS waits), so the net was a loss (profiles/r04_ab_recurrence.log).  Left as it was.
+    constexpr bool kRecur = L >= 16;
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
     const int d = tb.d, k = tb.k;
@@ -344,62 +340,45 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
             const double rnw = inv_norm(group_sum<L>(pw));
-            // (two copies of the loop, one per value of `refresh`: as a run-time condition inside one loop the compiler turns
-            // "if (refresh) px = fma(..)" into the fma and a select -- the dots the recurrence is there to save are formed anyway)
-            auto knot_loop = [&](auto refresh_c) {
-                constexpr bool kRefresh = decltype(refresh_c)::value;
 #pragma unroll
-                for (int r = 0; r < NK; ++r) {
-                    const double *row = knots + (size_t)r * DPAD;
-                    double pu = 0.0, px = 0.0;
-                    if constexpr (kSlotMajor) {
+            for (int r = 0; r < NK; ++r) {
+                const double *row = knots + (size_t)r * DPAD;
+                double pu = 0.0, px = 0.0;
+                if constexpr (kSlotMajor) {
 #pragma unroll
-                        for (int i = 0; i < N; i += 2) {
-                            const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
-                            pu = fma(kv.x, u[i], pu);
-                            if (kRefresh) px = fma(kv.x, x[i], px);
-                            pu = fma(kv.y, u[i + 1], pu);
-                            if (kRefresh) px = fma(kv.y, x[i + 1], px);
-                        }
-                    } else {
-                        // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
-                        // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
-                        // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
-#pragma unroll
-                        for (int i = 0; i < N; i += 2) {
-                            const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
-                            pu = fma(kv.x, u[i], pu);
-                            if (kRefresh) px = fma(kv.x, x[i], px);
-                            pu = fma(kv.y, u[i + 1], pu);
-                            if (kRefresh) px = fma(kv.y, x[i + 1], px);
-                        }
+                    for (int i = 0; i < N; i += 2) {
+                        const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
+                        pu = fma(kv.x, u[i], pu);
+                        if (refresh) px = fma(kv.x, x[i], px);
+                        pu = fma(kv.y, u[i + 1], pu);
+                        if (refresh) px = fma(kv.y, x[i + 1], px);
                     }
-                    const double au = group_sum<L>(pu) * rnw;
-                    double axr;
-                    if constexpr (kRefresh)
-                        axr = group_sum<L>(px);
-                    else
-                        axr = coef[2 * r];
-                    q[r] = (float)axr;
-                    q[NK + r] = (float)au;
-                    // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
-                    // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
-                    // the pair to one owner lane (round 2: 40 of the step's vector instructions)
-                    if constexpr (kRefresh)
-                        *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
-                    else
-                        coef[2 * r + 1] = au;
-                    // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
-                    if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
+                } else {
+                    // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
+                    // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
+                    // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
+#pragma unroll
+                    for (int i = 0; i < N; i += 2) {
+                        const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
+                        pu = fma(kv.x, u[i], pu);
+                        if (refresh) px = fma(kv.x, x[i], px);
+                        pu = fma(kv.y, u[i + 1], pu);
+                        if (refresh) px = fma(kv.y, x[i + 1], px);
+                    }
                 }
-            };
-            if constexpr (!kRecur) {
-                knot_loop(std::true_type{});
-            } else {
+                const double au = group_sum<L>(pu) * rnw;
+                const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
+                q[r] = (float)axr;
+                q[NK + r] = (float)au;
+                // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
+                // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
+                // the pair to one owner lane (round 2: 40 of the step's vector instructions)
                 if (refresh)
-                    knot_loop(std::true_type{});
+                    *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
                 else
-                    knot_loop(std::false_type{});
+                    coef[2 * r + 1] = au;
+                // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
+                if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
             }
 #pragma unroll
             for (int i = 0; i < N; i += 2) {
@@ -419,7 +398,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         // it where a_i.x is formed from x again) -- or the screen's own evaluation at theta = 0 after a refresh.
         float e_eval;
         bool finite;
-        if (refresh && kRecur || s == 0) {
+        if ((refresh && kRecur) || s == 0) {
             finite = c32s.finish32(u_thr, q);
             e_eval = c32s.eval_error(q);
         } else {
@@ -556,15 +535,9 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
 #pragma unroll
                 for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
             }
-            if (kRecur) {  // a . x' = c a.x + s a.u, knot r by lane r mod L of the group
+            if (kRecur && g == 0) {
 #pragma unroll
-                for (int r0 = 0; r0 < NK; r0 += L) {
-                    const int r = r0 + g;
-                    if (r < NK) {
-                        const double2 cu = *reinterpret_cast<const double2 *>(coef + 2 * r);
-                        coef[2 * r] = fma(cs, cu.x, sn * cu.y);
-                    }
-                }
+                for (int r = 0; r < NK; ++r) coef[2 * r] = fma(cs, coef[2 * r], sn * coef[2 * r + 1]);  // a . x' = c a.x + s a.u
             }
             ++steps_done;
             if ((a.samples != nullptr || STATS) && --until_keep == 0) {

@@ -94,7 +94,7 @@ struct ScreenVmf : FastVmf<D, KC> {
     // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
     static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
     static constexpr bool kCompact = false;
-    static constexpr bool kStageRows = KC <= 6;  // rows held back in LDS (screened_kernel): the wide mixtures have no register to spare
+    static constexpr bool kStageRows = false;  // (rows held back in LDS, screened_kernel<.., STAGE>: built for the Bingham targets, where it was measured)
     // S^2, K <= 3 (the README target, BASELINE cfg2): the threshold uniform is not parked -- an undecided try draws it again
     // from the counter-based stream -- which makes the parked state 15 words: five workgroups per CU instead of four (the
     // kernel needs 95 registers: five wavefronts per SIMD fit)
@@ -668,7 +668,7 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
 }
 
 // (measured: asking for two wavefronts per SIMD at d = 10 makes the curve kernel spill 73 registers: 45 -> 64 ms)
-template <int D, class TP, bool REPLAY, bool STATS = false>
+template <int D, class TP, bool REPLAY, bool STATS = false, bool STAGE = false>
 __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
 {
     using V = LaneVec<D>;
@@ -683,9 +683,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     // milliseconds apart) are written as partial sectors -- 1.39 x the bytes at D = 10.  With one chain per lane the LDS that
     // would park second chains is free: a lane holds a row back (at most kStageP - 1 of them) until the run of rows ends on
     // a sector boundary and stores the run at once (a.stage_rows, set by do_screened_run; same bytes in the same places).
-    // (built where second chains are parked, d <= 10: beyond, the rows' LDS would cost the one-per-lane kernels a workgroup)
-    // ... and where the target's kernel has the registers for it (TP::kStageRows: not the K >= 10 mixtures, which sit on their budget)
-    constexpr int kStageP = (!TP::kStageRows || D > 10 || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+    // A build of its own (STAGE; do_screened_run picks it for Bingham targets at d <= 10 when rows are kept that way): inside the
+    // plain kernels the extra state cost the two-chains-per-lane launches of the bench 0.6 % for nothing (measured).
+    constexpr int kStageP = (!STAGE || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
     double *stage = reinterpret_cast<double *>(park);  // [kStageP - 1][D][kBlock] doubles (nothing is parked in that mode)
     int32_t n_staged = 0;
     __syncthreads();
@@ -821,7 +821,11 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         const bool finite = tp.setup32(cur.x, cur.u, u_thr, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
         // verification (GSSS_VARIANT_FAST_VERIFY): an infinite margin leaves EVERY try undecided -- each is then decided in double
         // precision by decide(), and the run must reproduce the screened one bit for bit
-        if (a.screen == 2) cur.q[TP::kCoef32Floats - 1] = INFINITY;
+        // (built into the kernels of d = 11 .. 16, which have no all-double lane sibling to be compared with; d <= 10 is held to
+        // fast_kernel bit for bit instead, and a launch-wide flag kept live through the main loop cost those kernels 0.5 %)
+        if constexpr (D > 10) {
+            if (a.screen == 2) cur.q[TP::kCoef32Floats - 1] = INFINITY;
+        }
         if (shrink) {
             cur.hi = kTwoPi * u_th0;
             cur.lo = cur.hi - kTwoPi;
@@ -1002,10 +1006,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         // the chain taken up tries next -- or may, if its undecided try is decided a rejection: its unparked coefficients
         // are formed again (a chain that waits for set-up or for its move gets new ones there / needs none)
         if (Chain::kSkip > 0 && (cur.status == kReady || is_decide(cur.status))) tp.refill(cur.x, cur.u, reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));
-        if constexpr (Chain::kCompact) {
-            tp.retail(reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));  // the margin
-            if (a.screen == 2) cur.q[TP::kCoef32Floats - 1] = INFINITY;
-        }
+        if constexpr (Chain::kCompact) tp.retail(reinterpret_cast<float (&)[TP::kCoef32Floats]>(cur.q));  // the margin
     };
 
     // A slice's state, counters and flags go to the chunk's next slice: written through (SliceSched::hand_over), so that
@@ -1130,12 +1131,9 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     if constexpr (!REPLAY) {  // running statistics: a build of its own (the plain kernel carries none of it)
         if (rb.stats != nullptr) kern = screened_kernel<D, TP, false, true>;
     }
-    // (the most either packing asks for: two chains per lane with the second one parked, or one per lane with rows held back)
-    const size_t lds_most = lds > (TP::lds_doubles() + kTabLds + (size_t)3 * D * kBlock) * sizeof(double)
-                                ? lds : (TP::lds_doubles() + kTabLds + (size_t)3 * D * kBlock) * sizeof(double);
-    if (lds_most > 48 * 1024) {
+    if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_most);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GSSS_E_HIP;
@@ -1174,15 +1172,21 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     if (one_per_lane) {
         per_block = kBlock;
         lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
-        // chain-major retained rows that are not whole sectors are held back in that LDS until their run is (screened_kernel)
-        constexpr int kStageP = (!TP::kStageRows || D > 10 || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
-        const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
-        if (kStageP > 1 && rb.samples != nullptr && rb.keep_rows > 0 && !(env_stage && env_stage[0] == '0')) {
-            // ... unless that LDS would cost a resident workgroup (bytes at 0.3 % of the HBM peak are not worth a wavefront)
-            const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
-            if (resident_workgroups(reinterpret_cast<const void *>(kern), lds_staged) >= resident_workgroups(reinterpret_cast<const void *>(kern), lds)) {
-                stage_rows = true;
-                lds = lds_staged;
+        // chain-major retained rows that are not whole sectors are held back in that LDS until their run is (screened_kernel<.., STAGE>)
+        if constexpr (!REPLAY && TP::kStageRows && D <= 10 && D % 4 != 0) {
+            constexpr int kStageP = (D % 2 == 0) ? 2 : 4;
+            const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
+            if (rb.samples != nullptr && rb.keep_rows > 0 && rb.stats == nullptr && !(env_stage && env_stage[0] == '0')) {
+                // ... unless that LDS would cost a resident workgroup (bytes at 0.3 % of the HBM peak are not worth a wavefront)
+                auto kern_staged = screened_kernel<D, TP, false, false, true>;
+                const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
+                if (resident_workgroups(reinterpret_cast<const void *>(kern_staged), lds_staged) >= resident_workgroups(reinterpret_cast<const void *>(kern), lds)) {
+                    if (lds_staged > 48 * 1024)
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged);
+                    stage_rows = true;
+                    lds = lds_staged;
+                    kern = kern_staged;
+                }
             }
         }
     }

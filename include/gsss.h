@@ -56,8 +56,8 @@ extern "C" {
  * margin, double precision where the margin does not decide: same chains); this value forces the all-double kernels */
 #define GSSS_VARIANT_FAST_DOUBLE 100
 /* verification: the library's choice of kernel with the verdicts of its single-precision screen ignored where that kernel
- * can do so (the group-speculative curve-vMF kernel: every try is decided in double precision by the same arithmetic, so
- * the run must reproduce variant 0 bit for bit); other kernels run as with variant 0 */
+ * can do so (the group-speculative curve-vMF kernel and the lane kernels of d = 11 .. 16: every try is decided in double
+ * precision by the same arithmetic, so the run must reproduce variant 0 bit for bit); other kernels run as with variant 0 */
 #define GSSS_VARIANT_FAST_VERIFY 101
 
 /* return codes */

@@ -781,7 +781,8 @@ def test_screened_equals_double(gs, name, n_chains, n_steps, sampler):
     probe = cls(pdf, x0[:1], seed=5, mode="fast", placement="packed")
     spec = probe._lib.gsss_kernel_name(probe._target_dev.handle, 1, 0, 1).decode().startswith("curvespec_kernel")
     # "verify": the default kernel with an infinite margin -- every try decided in double precision by the kernel's own
-    # arithmetic -- must give the screened run's bits (round 4: the lane kernels too, not only the group kernels)
+    # arithmetic -- must give the screened run's bits (the group kernels; round 4: the lane kernels of d = 11 .. 16, which have no
+    # all-double lane sibling; at d <= 10 the variant is not built in and the run is the default one)
     for screen in (True, False, "verify"):
         s = cls(pdf, x0, seed=5, mode="fast", placement="packed", screen=screen)
         name_k = s._lib.gsss_kernel_name(s._target_dev.handle, 1, {True: 0, False: 100, "verify": 101}[screen], 1).decode()
@@ -1044,10 +1045,11 @@ def test_long_launch_gets_longer_slices(gs, monkeypatch):
     assert int((out["whole"][4] != 0).sum()) == 0
 
 
-@pytest.mark.parametrize("name", ["vmfmix_readme", "bingham_d10_vmax30", "bingham_d5_dense", "vmfmix_d10_k5_kappa100", "vmfmix_d4_k4_weighted"])
+@pytest.mark.parametrize("name", ["bingham_d10_vmax30", "bingham_d5_dense", "binghamfisher_d5", "binghamfisher_d6", "vmfmix_readme"])
 def test_rows_held_back_in_lds_land_where_they_belong(gs, name, monkeypatch):
-    """One chain per lane, (chains, draws, dims) output: rows of 8 d bytes that do not end on a 32-byte sector are held back in LDS
-    until their run does (screened_kernel, RunBlock::stage_rows) -- fewer partial sectors, the SAME array: with the staging
+    """One chain per lane, (chains, draws, dims) output, Bingham targets at d <= 10 (the mixture runs the plain kernel either way:
+    the control): rows of 8 d bytes that do not end on a 32-byte sector are held back in LDS
+    until their run does (screened_kernel<.., STAGE>, RunBlock::stage_rows) -- fewer partial sectors, the SAME array: with the staging
     switched off (GSSS_STAGE_ROWS=0) every retained row of every chain is bit-identical, for odd and even row offsets (sample()
     starts at row 1), thinning, runs of rows split over launches (the Python classes cap a launch at 4096 steps) and chains that
     stop early (max_tries)."""
