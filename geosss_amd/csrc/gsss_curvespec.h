@@ -41,6 +41,12 @@ namespace gsss {
 #ifndef GSSS_CS_WAVES_BIG
 #define GSSS_CS_WAVES_BIG 2
 #endif
+#ifndef GSSS_CS_KNOT_PIPE
+#define GSSS_CS_KNOT_PIPE 1  // knot rows read from LDS one row ahead of their products (more than four components per lane)
+#endif
+#ifndef GSSS_CS_KNOT_BARRIER
+#define GSSS_CS_KNOT_BARRIER 2  // knots between scheduling barriers in the knot-dot loop
+#endif
 
 template <int L, int NK>
 __host__ __device__ constexpr int curvespec_scratch_doubles()
@@ -340,45 +346,90 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
             const double rnw = inv_norm(group_sum<L>(pw));
+            // Round 4: the knot rows software-pipelined -- row r + 1 is read from LDS while row r is multiplied (N more registers, the
+            // same products in the same order, the same bits).  The two-wavefront builds wait on LDS with nobody to switch to (vector
+            // pipes 0.83 busy): d = 24 28.60 -> 28.20 ms, d = 50 34.87 -> 33.96, d = 200 97.8 -> 95.96 per 10^8 chain-steps
+            // (profiles/r04_ab_knot_pipeline.log; scheduling barriers every 1 / 3 / 5 knots or none: 0 .. +3 %, left at 2).
+            constexpr bool kPipe = GSSS_CS_KNOT_PIPE && Q >= 2;
+            if constexpr (kPipe) {
+                // (sixteen lanes x sixteen components: half a row ahead -- a whole one spills 12 bytes a lane at two wavefronts per SIMD)
+                constexpr int kAhead = (L >= 16 && Q >= 4) ? N / 4 : N / 2;
+                auto load_part = [&](int r, double2 (&dst)[N / 2], int from, int to) {
+                    const double *row = knots + (size_t)r * DPAD;
 #pragma unroll
-            for (int r = 0; r < NK; ++r) {
-                const double *row = knots + (size_t)r * DPAD;
-                double pu = 0.0, px = 0.0;
-                if constexpr (kSlotMajor) {
+                    for (int h = 0; h < N / 2; ++h)
+                        if (h >= from && h < to)
+                            dst[h] = kSlotMajor ? *reinterpret_cast<const double2 *>(row + 2 * (h * L + g))
+                                                : *reinterpret_cast<const double2 *>(row + V::comp(g, 2 * h));
+                };
+                double2 cur_row[N / 2], nxt_row[N / 2];
+                load_part(0, cur_row, 0, N / 2);
+#pragma unroll
+                for (int r = 0; r < NK; ++r) {
+                    if (r + 1 < NK) load_part(r + 1, nxt_row, 0, kAhead);
+                    double pu = 0.0, px = 0.0;
 #pragma unroll
                     for (int i = 0; i < N; i += 2) {
-                        const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
+                        const double2 kv = cur_row[i / 2];
                         pu = fma(kv.x, u[i], pu);
                         if (refresh) px = fma(kv.x, x[i], px);
                         pu = fma(kv.y, u[i + 1], pu);
                         if (refresh) px = fma(kv.y, x[i + 1], px);
                     }
-                } else {
-                    // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
-                    // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
-                    // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
+                    const double au = group_sum<L>(pu) * rnw;
+                    const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
+                    q[r] = (float)axr;
+                    q[NK + r] = (float)au;
+                    if (refresh)
+                        *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);
+                    else
+                        coef[2 * r + 1] = au;
 #pragma unroll
-                    for (int i = 0; i < N; i += 2) {
-                        const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
-                        pu = fma(kv.x, u[i], pu);
-                        if (refresh) px = fma(kv.x, x[i], px);
-                        pu = fma(kv.y, u[i + 1], pu);
-                        if (refresh) px = fma(kv.y, x[i + 1], px);
-                    }
+                    for (int h = 0; h < kAhead; ++h) cur_row[h] = nxt_row[h];
+                    __builtin_amdgcn_sched_barrier(0);  // one row (or half of one) ahead, no further
+                    if (kAhead < N / 2 && r + 1 < NK) load_part(r + 1, cur_row, kAhead, N / 2);
                 }
-                const double au = group_sum<L>(pu) * rnw;
-                const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
-                q[r] = (float)axr;
-                q[NK + r] = (float)au;
-                // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
-                // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
-                // the pair to one owner lane (round 2: 40 of the step's vector instructions)
-                if (refresh)
-                    *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
-                else
-                    coef[2 * r + 1] = au;
-                // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
-                if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
+            } else {
+#pragma unroll
+                for (int r = 0; r < NK; ++r) {
+                    const double *row = knots + (size_t)r * DPAD;
+                    double pu = 0.0, px = 0.0;
+                    if constexpr (kSlotMajor) {
+#pragma unroll
+                        for (int i = 0; i < N; i += 2) {
+                            const double2 kv = *reinterpret_cast<const double2 *>(row + 2 * ((i / 2) * L + g));
+                            pu = fma(kv.x, u[i], pu);
+                            if (refresh) px = fma(kv.x, x[i], px);
+                            pu = fma(kv.y, u[i + 1], pu);
+                            if (refresh) px = fma(kv.y, x[i + 1], px);
+                        }
+                    } else {
+                        // component order: a lane's quads are 32 contiguous bytes, read as two 16-byte halves (ds_read_b128: 4 LDS
+                        // cycles per wavefront; left to itself the compiler, which cannot see the alignment behind the opaque
+                        // offset, reads them with ds_read2_b64: 8 cycles for the same bytes)
+#pragma unroll
+                        for (int i = 0; i < N; i += 2) {
+                            const double2 kv = *reinterpret_cast<const double2 *>(row + V::comp(g, i));
+                            pu = fma(kv.x, u[i], pu);
+                            if (refresh) px = fma(kv.x, x[i], px);
+                            pu = fma(kv.y, u[i + 1], pu);
+                            if (refresh) px = fma(kv.y, x[i + 1], px);
+                        }
+                    }
+                    const double au = group_sum<L>(pu) * rnw;
+                    const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
+                    q[r] = (float)axr;
+                    q[NK + r] = (float)au;
+                    // parked for decide() and the recurrence.  EVERY lane of the group stores the pair: they hold the same bits after
+                    // the group sums, same address, same value -- an LDS instruction instead of the 4 selects per knot that routed
+                    // the pair to one owner lane (round 2: 40 of the step's vector instructions)
+                    if (refresh)
+                        *reinterpret_cast<double2 *>(coef + 2 * r) = make_double2(axr, au);  // (one 16-byte store)
+                    else
+                        coef[2 * r + 1] = au;
+                    // two knots at a time: left alone the scheduler runs all NK reduction chains side by side (4 NK registers)
+                    if (GSSS_CS_KNOT_BARRIER > 0 && r % GSSS_CS_KNOT_BARRIER == GSSS_CS_KNOT_BARRIER - 1) __builtin_amdgcn_sched_barrier(0);  // (five knots at a time: measured, no change)
+                }
             }
 #pragma unroll
             for (int i = 0; i < N; i += 2) {
