@@ -507,6 +507,7 @@ def main(argv=None):
     if env_world is None and args.gpus > 1:
         return self_launch(args, argv)              # nothing below has run: no torch, no HIP in this process
     world = int(env_world or "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL needs it on this driver; set before torch loads HIP)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
