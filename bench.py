@@ -419,6 +419,19 @@ def kept_buffer(torch, layout, n, S, thin, d):
     return torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda"), dict()
 
 
+def numpy_stream_kernel_name(gs, sampler, packed_name):
+    """The kernel a packed launch on numpy's stream runs (gsss_kernel_name names the library stream's): the screened lane kernel's
+    NUMPY build for mixtures of K <= 10 and Bingham targets at d <= 10 (gsss_fast_vmf_lane.h, gsss_fast_bingham.hip), else the
+    all-double lane kernel's."""
+    import re
+    m = re.match(r"screened_kernel<(\d+), Screen(Vmf<\d+, (\d+)>|Bingham\w*<\d+>)>", packed_name)
+    if m and int(m.group(1)) <= 10 and (m.group(3) is None or int(m.group(3)) <= 10):
+        return packed_name[:-1] + ", NUMPY>"
+    lib = gs._lib.load()
+    name = lib.gsss_kernel_name(sampler._target_dev.handle, gs._lib.MODE_FAST, gs._lib.VARIANT_FAST_DOUBLE, 1).decode()
+    return name[:-1] + ", NUMPY>" if name.startswith("fast_kernel") else name
+
+
 def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="philox"):
     """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload.  rng="numpy": the same launch
     on numpy's own stream, one generator per chain, packed (fast_kernel<..., NUMPY>)."""
@@ -429,10 +442,9 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="
     thin = 100
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
-    variant = gs._lib.VARIANT_FAST_DOUBLE if rng == "numpy" else 0   # (the name of the kernel that serves numpy's stream: the all-double lane kernel)
-    kernel = lib.gsss_kernel_name(s._target_dev.handle, mode_id, variant, 1).decode()
+    kernel = lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode()
     if rng == "numpy":
-        kernel = kernel.replace(">>", ">, NUMPY>") if kernel.startswith("fast_kernel") else kernel
+        kernel = numpy_stream_kernel_name(gs, s, kernel)
     layout = pick_layout(layout, kernel, d, thin)
     kept, kw = kept_buffer(torch, layout, n, S, thin, d)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -633,7 +645,8 @@ def main(argv=None):
                        "kept_rows_layout": layout,
                        "csrc_sha256": source_digest(),
                        "mode": sampler.mode,
-                       "kernel": lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode(),
+                       "kernel": (numpy_stream_kernel_name(gs, sampler, lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, 0, 1).decode())
+                                  if args.rng == "numpy" else lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode()),
                        "sharding": f"{world} x independent chain blocks, final states all-gathered over RCCL"
                        if world > 1 else "single GPU"},
             "tries_per_step": tries / total_steps, "chains_in_error": bad,

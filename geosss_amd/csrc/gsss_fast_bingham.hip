@@ -18,6 +18,8 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
             if (rb.screen) GSSS_PROBE(true, "screened_kernel<%d, ScreenBingham<%d>>", D, D); \
             GSSS_PROBE(true, "fast_kernel<%d, FastBingham<%d>>", D, D); \
         }                                                          \
+        if (rb.screen && !rb.spread && rb.rng_state != nullptr && !replay)   /* numpy's stream, packed: the screened kernel too */ \
+            return compact ? do_screened_numpy<D, ScreenBinghamDiag<D>>(tb, rb, st) : do_screened_numpy<D, ScreenBingham<D>>(tb, rb, st); \
         if (!screen) return do_fast<D, FastBingham<D>>(tb, rb, replay, st); \
         if (compact) return replay ? do_screened_run<D, ScreenBinghamDiag<D>, true>(tb, rb, st) : do_screened_run<D, ScreenBinghamDiag<D>, false>(tb, rb, st); \
         return replay ? do_screened_run<D, ScreenBingham<D>, true>(tb, rb, st) : do_screened_run<D, ScreenBingham<D>, false>(tb, rb, st); \

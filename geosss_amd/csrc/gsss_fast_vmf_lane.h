@@ -18,6 +18,11 @@ template <int D, int KS, int KF>
 static int run_lane_vmf(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
 {
     const bool screen = rb.screen && !rb.spread && rb.rng_state == nullptr && tb.scale <= kScreenMaxKappa;
+    // numpy's stream for a packed ensemble: the screened kernel too (round 4; K <= 10 -- the widest bucket stays all-double)
+    if constexpr (KS <= 10) {
+        if (rb.screen && !rb.spread && rb.rng_state != nullptr && !replay && tb.scale <= kScreenMaxKappa)
+            return do_screened_numpy<D, ScreenVmf<D, KS>>(tb, rb, st);
+    }
     if (!screen) return do_fast<D, FastVmf<D, KF>>(tb, rb, replay, st);
     return replay ? do_screened_run<D, ScreenVmf<D, KS>, true>(tb, rb, st) : do_screened_run<D, ScreenVmf<D, KS>, false>(tb, rb, st);
 }

@@ -95,6 +95,8 @@ struct ScreenVmf : FastVmf<D, KC> {
     static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
     static constexpr bool kCompact = false;
     static constexpr bool kStageRows = false;  // (rows held back in LDS, screened_kernel<.., STAGE>: built for the Bingham targets, where it was measured)
+    static constexpr int kNumpyWaves = (KC >= 10 || (D >= 9 && KC >= 6)) ? 2 : ((D <= 4 && KC <= 3) ? 4 : 3);  // wavefronts per SIMD of the numpy-stream build: without scratch, but for the smallest
+                                                   // shapes, where a fourth wavefront is worth 12-20 spilled bytes (README target 40.9 -> 38.7 ms)
     // S^2, K <= 3 (the README target, BASELINE cfg2): the threshold uniform is not parked -- an undecided try draws it again
     // from the counter-based stream -- which makes the parked state 15 words: five workgroups per CU instead of four (the
     // kernel needs 95 registers: five wavefronts per SIMD fit)
@@ -227,6 +229,7 @@ struct ScreenBingham : FastBingham<D> {
     static constexpr int kCoef32Floats = 6;
     static constexpr int kParkSkip = 0, kMinWaves = D > 10 ? 2 : 1, kTradeMin = 1;
     static constexpr bool kCompact = false, kRegenThr = false, kStageRows = true;
+    static constexpr int kNumpyWaves = D >= 7 ? 2 : 3;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void coeffs(Coef &cf, const double (&x)[D], const double (&u)[D]) const
@@ -299,6 +302,7 @@ struct ScreenBinghamDiag {
     static constexpr int kCoef32Floats = 4;  // q0 = -log U, q1 = qxu, q2 = (quu - qxx) - log U | margin
     static constexpr int kParkSkip = 0, kMinWaves = D >= 14 ? 2 : (D >= 9 ? 3 : 1), kTradeMin = 1;  // (d >= 14 spills at three)
     static constexpr bool kCompact = true, kRegenThr = true, kStageRows = true;
+    static constexpr int kNumpyWaves = 3;
     const double *a;  // LDS [D]: the diagonal of A
     struct Coef {
         double qxx, qxu, quu;
@@ -506,6 +510,7 @@ struct ScreenCurve : FastCurve<D, NK> {
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
     static constexpr bool kCompact = false, kRegenThr = false, kStageRows = false;
+    static constexpr int kNumpyWaves = 2;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
     Curve32<NK> c32;
@@ -668,9 +673,16 @@ __device__ __forceinline__ void lds_trade(float &a, float &b, unsigned long long
 }
 
 // (measured: asking for two wavefronts per SIMD at d = 10 makes the curve kernel spill 73 registers: 45 -> 64 ms)
-template <int D, class TP, bool REPLAY, bool STATS = false, bool STAGE = false>
-__global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves) screened_kernel(TargetBlock tb, RunBlock a)
+// NUMPY (round 4): the draws come from numpy's own PCG64 / ziggurat stream (RunBlock::rng_state, NumpyDraws) at the replay
+// path's consumption points -- the reference's order: d normals, the threshold uniform, theta_0, then a uniform per try that
+// is made -- a generator per chain, one chain per lane, the ziggurat tables where second chains would be parked.  The tries are
+// screened like the library stream's: the same accept decisions as fast_kernel<.., NUMPY>, hence the reference's chain from its
+// seed (tests/test_hip_parity.py::test_reference_chain_from_seed[packed], test_numpy_stream_lane_kernel).
+template <int D, class TP, bool REPLAY, bool STATS = false, bool STAGE = false, bool NUMPY = false>
+__global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (NUMPY ? TP::kNumpyWaves : TP::kMinWaves))
+    screened_kernel(TargetBlock tb, RunBlock a)  // (NUMPY: the generator's state and the ziggurat's temporaries on top of the plain kernel's registers)
 {
+    static_assert(!NUMPY || (REPLAY && !STAGE), "numpy's stream is a sequential source: it is read where the replay buffer is");
     using V = LaneVec<D>;
     using Chain = ScreenChain<D, TP>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -678,6 +690,8 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     tp.stage(lds, tb);
     const fm::Tables tab = stage_tables(lds + TP::lds_doubles());
     unsigned long long *park = reinterpret_cast<unsigned long long *>(lds + TP::lds_doubles() + kTabLds) + threadIdx.x;
+    NumpyDraws<V> nd;
+    if constexpr (NUMPY) nd.stage(lds + TP::lds_doubles() + kTabLds);
     // Retained rows in the reference's (chains, draws, dims) order are 8 D bytes at an 8 D byte stride: for D not a multiple of
     // four a row ends inside a 32-byte sector, and rows that leave one at a time (a chain keeps a row every `thin` steps,
     // milliseconds apart) are written as partial sectors -- 1.39 x the bytes at D = 10.  With one chain per lane the LDS that
@@ -694,7 +708,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     // This workgroup's work: its chunk of chains for the whole launch -- or, in the sliced partial round of a launch
     // (plan_partial_round, gsss_device.h), the (chunk, step slice) of the ticket it draws.  A chain's step count runs over the
     // launch's steps [s_begin, n_steps): counters of the stream and retained rows need nothing else.
-    constexpr int kChunk = screen_parks<D, TP>() ? 2 * kBlock : kBlock;  // chains per workgroup
+    constexpr int kChunk = (screen_parks<D, TP>() && !NUMPY) ? 2 * kBlock : kBlock;  // chains per workgroup
     __shared__ uint32_t sched_word[4];
     const bool sliced = a.sched != nullptr && (int32_t)blockIdx.x >= a.sched_first;
     uint32_t chunk = blockIdx.x;
@@ -710,7 +724,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
     const double rcp_thin = 1.0 / (double)thin;  // (compact chains: the retained row follows from the step count)
     const int32_t max_tries = a.max_tries < (1 << 25) ? a.max_tries : (1 << 25) - 1;  // t shares a word with the flags
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
-    constexpr bool kPark = screen_parks<D, TP>();
+    constexpr bool kPark = screen_parks<D, TP>() && !NUMPY;  // (a generator per chain: one chain per lane)
     constexpr int kPerBlock = kPark ? 2 * kBlock : kBlock;
     // (one_per_lane: kBlock chains per workgroup, the lane's second slot stays empty -- a chain id past the ensemble)
     const int32_t id0 = (int32_t)chunk * (a.one_per_lane ? kBlock : kPerBlock) + (int32_t)threadIdx.x;
@@ -729,6 +743,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         return dr;
     };
     auto replay_take = [&]() -> double {
+        if constexpr (NUMPY) return nd.next_double();
         if (cur.cursor >= (int32_t)a.replay_stride) {
             cur.err |= GSSS_CHAIN_REPLAY_EXHAUSTED;
             return 0.5;
@@ -760,6 +775,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         cur.cursor = 0;
         cur.t = 0;
         cur.status = (valid && n_steps > s_begin) ? kPending : kDone;
+        if constexpr (NUMPY) nd.init(a, cc, D);
         if (sliced && valid) {
             if (SliceSched::dead(a, a.one_per_lane ? kBlock : kChunk)[cc] != 0) cur.status = kDone;  // stopped with an error flag in an earlier slice
             if (timed_out && cur.status != kDone) {                             // cannot happen (SliceSched::take)
@@ -774,7 +790,10 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         double u_thr, u_th0;
         uint32_t w_phi = 0u;  // S^2, Philox stream: the angle word of the tangent direction
         if (REPLAY) {
-            if (cur.cursor + D <= (int32_t)a.replay_stride) {
+            if constexpr (NUMPY) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) cur.u[j] = nd.standard_normal();
+            } else if (cur.cursor + D <= (int32_t)a.replay_stride) {
 #pragma unroll
                 for (int j = 0; j < D; ++j)
                     cur.u[j] = a.replay[(size_t)chain_id() * a.replay_stride + cur.cursor + j];
@@ -1026,6 +1045,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         const int32_t c = chain_id();
         if (c >= n) return;
         if (kStageP > 1 && n_staged > 0) unstage(&a.samples[sample_index(a, cur.row, 0, D, c)]);  // (the chain's next row starts there)
+        if constexpr (NUMPY) nd.finish(a, c, true);
 #pragma unroll
         for (int j = 0; j < D; ++j) put_out(&a.state[(size_t)j * n + c], cur.x[j]);
         if (a.n_reject) put_out(&a.n_reject[c], a.n_reject[c] + ((int64_t)cur.n_try - (cur.steps_done - s_begin)));
@@ -1121,6 +1141,34 @@ __global__ void __launch_bounds__(kBlock, (STATS || REPLAY) ? 1 : TP::kMinWaves)
         flush();
     }
     if (sliced) SliceSched::publish<kThrough>(a, sched_word);
+}
+
+// numpy's stream through the screened kernel: one lane per chain, unsliced (a generator's state lives in its lane for the launch)
+template <int D, class TP>
+int do_screened_numpy(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
+{
+    const size_t lds = (TP::lds_doubles() + kTabLds + NumpyDraws<LaneVec<D>>::kLdsDoubles) * sizeof(double);
+    auto kern = rb.stats != nullptr ? screened_kernel<D, TP, true, true, false, true> : screened_kernel<D, TP, true, false, false, true>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GSSS_E_HIP;
+        }
+    }
+    RunBlock rbl = rb;
+    rbl.one_per_lane = 1;
+    rbl.stage_rows = 0;
+    rbl.sched = nullptr;
+    const int64_t grid = (rb.n_chains + kBlock - 1) / kBlock;
+    last_launch() = LaunchInfo{grid, 0, 0.0};
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, tb, rbl);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("screened kernel launch failed: %s", hipGetErrorString(e));
+        return GSSS_E_HIP;
+    }
+    return GSSS_OK;
 }
 
 template <int D, class TP, bool REPLAY>

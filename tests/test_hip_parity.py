@@ -437,7 +437,8 @@ def test_numpy_stream_many_chains(gs, oracle):
 
 
 @pytest.mark.parametrize("name,n_chains", [("vmfmix_readme", 2500), ("vmfmix_d10_k5_kappa100", 700), ("bingham_d10_vmax30", 900),
-                                           ("curve_d10_kappa800", 600), ("curve_d24_kappa800", 300)])
+                                           ("vmfmix_k10_kappa500", 1000), ("vmfmix_d4_k4_weighted", 800), ("bingham_d5_dense", 800),
+                                           ("binghamfisher_d6", 600), ("curve_d10_kappa800", 600), ("curve_d24_kappa800", 300)])
 @pytest.mark.parametrize("sampler", ["shrink", "reject"])
 def test_numpy_stream_lane_kernel(gs, oracle, name, n_chains, sampler):
     """numpy's stream for LARGE ensembles of the lane-per-chain shapes: one lane per chain, each with its own PCG64 / ziggurat
@@ -452,8 +453,15 @@ def test_numpy_stream_lane_kernel(gs, oracle, name, n_chains, sampler):
     kind = oracle.REJECT if sampler == "reject" else oracle.SHRINK
     want = oracle.run(tgt, x0, n_steps, numpy_seed=list(root.spawn(n_chains)), sampler=kind)
     cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    # round 4: the screened lane kernel serves numpy's stream too (screened_kernel<.., NUMPY>: mixtures K <= 10 and Bingham
+    # targets); screen=False is the all-double fast_kernel<.., NUMPY> of round 3 -- the same chains bit for bit
+    a = cls(pdf, x0, np.random.SeedSequence(2024), rng="numpy", mode="fast", placement="packed", screen=False)
+    kept_a = a.advance(n_steps, thin=1)
     s = cls(pdf, x0, np.random.SeedSequence(2024), rng="numpy", mode="fast", placement="packed")
-    got = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
+    kept_s = s.advance(n_steps, thin=1)
+    import torch
+    assert torch.equal(kept_s, kept_a) and torch.equal(s._n_tries, a._n_tries) and torch.equal(s._rng_state, a._rng_state)
+    got = kept_s.permute(2, 0, 1).cpu().numpy()
     assert np.max(np.abs(got - want["samples"])) < TOL
     assert np.array_equal(s.n_tries_per_chain, want["n_tries"])
     e = cls(pdf, x0, np.random.SeedSequence(2024), rng="numpy", mode="exact")
