@@ -224,7 +224,7 @@ def test_wide_lane_kernels_do_not_spill():
     for src, dims in (("gsss_fast_vmf_d12.hip", (12,)), ("gsss_fast_vmf_d16.hip", (16,)), ("gsss_fast_bingham_wide_a.hip", (11, 12, 13)),
                       ("gsss_fast_bingham_wide_b.hip", (14, 15, 16))):
         for name, r in build.resource_usage(src).items():
-            if "screened_kernel" in name and "Lb0ELb0E" in name:                  # <.., replay = false, stats = false>
+            if "screened_kernel" in name and "Lb0ELb0ELb0ELb0E" in name:          # <.., replay, stats, stage, numpy: all false>
                 seen += 1
                 assert r["scratch"] == 0 and r["occupancy"] >= 2, (name, r)
     assert seen == 2 * 3 + 2 * 6
