@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         sg[4 * i + 3] = 0.0;
     }
     __syncthreads();
-    Curve32<NK> c32;
+    Curve32<NK, (L < 16)> c32;
     c32.stage(reinterpret_cast<float4 *>(sg + 4 * (NK - 1)), sg, k - 1, tb.kappa);
     double *scr = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (threadIdx.x / L);
     double *ring = scr + 2;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         const double *knots = lds + opaque;
         Scalar scl = sc;
         scl.seg = knots + (size_t)NK * DPAD;
-        Curve32<NK> c32s = c32;
+        Curve32<NK, (L < 16)> c32s = c32;
         c32s.seg32 = reinterpret_cast<const float4 *>(knots + (size_t)NK * DPAD + 4 * (NK - 1));
         // ---------------- draws of the step
         double u[N], u_thr, u_th0;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
         // ---------------- a_r . u = (a_r . w) / |w|, a_r . x; single-precision pack; the doubles parked for decide()
         const bool refresh = !kRecur || s == 0 || ((step0 + (uint64_t)s) % kCoefRefresh) == 0;
-        float q[Curve32<NK>::kFloats];
+        float q[Curve32<NK, (L < 16)>::kFloats];
         {
             double pw = 0.0;
 #pragma unroll

@@ -371,7 +371,7 @@ struct ScreenBinghamDiag {
 
 // The single-precision side of the curve-vMF screen, independent of how the chain's components are laid out
 // (lane kernels: ScreenCurve below; lane groups: gsss_curvespec.h).  q = [a_i.x | a_i.u | thr / kappa | margin].
-template <int NK>
+template <int NK, bool PACKED = false>
 struct Curve32 {
     const float4 *seg32;  // LDS [NK-1]: cos, sin, 1 / (sin + 1e-10) per segment in single precision (read as one broadcast b128)
     float inv_sin_min;
@@ -391,9 +391,73 @@ struct Curve32 {
     // margin, eval_error); continuous across the branch boundaries (t* = 0: |P y| / sin = a.y; t* = theta_g: = b.y), so the
     // Lipschitz bound of the margin holds whichever branch the single-precision evaluation takes.  16 instead of 34 vector
     // instructions a segment (no three-way select, v_sqrt instead of v_rsq and two products).
+    // Round 4: TWO segments per instruction.  Segment g needs a_g.y and a_{g+1}.y; with H = NK / 2 and Z_i = (a_i.y, a_{i+H}.y)
+    // held as one register pair, segments g and g + H are the two halves of the same packed operations on (Z_g, Z_{g+1}):
+    // v_pk_mul_f32 / v_pk_fma_f32 form A, B, A^2 + B^2, cos(theta_g) h and h / sin for both at once (the IEEE operations of
+    // the scalar loop, hence its bits; square roots, comparisons, selects and maxima stay one per segment): 8 instead of 15
+    // vector instructions a segment, and the 2 NK products of a.y = c a.x + s a.u two at a time.  The constants rest in LDS
+    // pair-major: seg32[g] = (cos_g, cos_{g+H}, sin_g, sin_{g+H}), then H pairs (1 / sin_g, 1 / sin_{g+H}).
+    // Measured (profiles/r04_ab_packed_segments.log, ms per 10^8 chain-steps): d = 10 20.70 -> 20.27, d = 24 28.24 -> 27.68, d = 50
+    // 34.00 -> 33.92, d = 200 96.66 -> 97.78: PACKED for the four- and eight-lane groups, not for sixteen (nor the d = 3 lane kernel,
+    // unmeasured).
+    static constexpr int kH = NK / 2;  // segments per half (NK = 10: 0..4 | 5..9, the tenth a padding one; NK = 17: 0..7 | 8..15)
+    static_assert(6 * kH <= 4 * (NK - 1), "the pair-major constants fit where the per-segment ones were");
+    typedef float f2 __attribute__((ext_vector_type(2)));
     template <bool PRELOAD = false>
     __device__ __forceinline__ float best32(const float (&q)[kFloats], float c, float s) const
     {
+      if constexpr (PACKED) {
+        const f2 c2 = {c, c}, s2 = {s, s};
+        auto qv = [&](int i) -> float { return i < NK ? q[i] : 0.0f; };
+        auto qu = [&](int i) -> float { return i < NK ? q[NK + i] : 0.0f; };
+        auto zpair = [&](int i) -> f2 {  // a.y = fma(c, a.x, s * a.u), as the scalar loop forms it
+            const f2 ax = {qv(i), qv(i + kH)}, au = {qu(i), qu(i + kH)};
+            return __builtin_elementwise_fma(c2, ax, s2 * au);
+        };
+        f2 ay = zpair(0);
+        const float2 *rd = reinterpret_cast<const float2 *>(seg32 + kH);
+        float4 pre[PRELOAD ? kH : 1];
+        float2 prer[PRELOAD ? kH : 1];
+        if (PRELOAD) {
+#pragma unroll
+            for (int g = 0; g < kH; ++g) {
+                pre[g] = seg32[g];
+                prer[g] = rd[g];
+            }
+        }
+        float best = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < kH; ++g) {
+            const float4 sg = PRELOAD ? pre[PRELOAD ? g : 0] : seg32[g];
+            const float2 rr = PRELOAD ? prer[PRELOAD ? g : 0] : rd[g];
+            const f2 ct = {sg.x, sg.y}, st = {sg.z, sg.w}, rden = {rr.x, rr.y};
+            const f2 by = zpair(g + 1);
+            const f2 A = ay * st;
+            const f2 B = __builtin_elementwise_fma(-ay, ct, by);
+            const f2 h2 = __builtin_elementwise_fma(A, A, B * B);
+            const f2 h = {__builtin_amdgcn_sqrtf(h2.x), __builtin_amdgcn_sqrtf(h2.y)};
+            const f2 cth = ct * h, hr = h * rden;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int seg = g + half * kH;
+                if (seg + 1 < NK) {  // (NK = 10: segment 9 does not exist)
+                    const float Ah = half ? A.y : A.x, Bh = half ? B.y : B.x, ayh = half ? ay.y : ay.x, byh = half ? by.y : by.x;
+                    const bool before_b = Ah >= (half ? cth.y : cth.x);  // t* <= theta_g
+                    const bool inside = (Bh > 0.0f) & before_b;
+                    float v = inside ? (half ? hr.y : hr.x) : ayh;
+                    if (seg == nseg - 1) {                               // (uniform) the last segment: b where the reference clips to it
+                        const bool at_a = (Bh < 0.0f) | ((Bh == 0.0f) & (Ah >= 0.0f));
+                        v = fmaxf(v, (!before_b & !at_a) ? byh : -INFINITY);
+                    }
+                    best = fmaxf(best, seg < nseg ? v : -INFINITY);
+                }
+            }
+            ay = by;
+            __builtin_amdgcn_sched_barrier(0);  // two segments at a time, as before (all of them side by side cost registers the callers do not have)
+        }
+        return fminf(best, 1.0f);
+      } else {
+
         float best = -INFINITY;
         float ay = fmaf(c, q[0], s * q[NK]);
         // PRELOAD (kernels with registers to spare: two wavefronts per SIMD): all segments' constants are read in one go -- one
@@ -429,6 +493,7 @@ struct Curve32 {
             for (int g = 0; g + 1 < NK; ++g) asm volatile("" ::"v"(pre[g].w));
         }
         return fminf(best, 1.0f);  // (the reference clips every y . nearest to [-1, 1]; the maximum of unit vectors' dots is >= -1)
+      }
     }
     // error bound of one best32 evaluation with the coefficients q[0 .. 2 NK)
     __device__ __forceinline__ float eval_error(const float (&q)[kFloats]) const
@@ -485,8 +550,16 @@ struct Curve32 {
     // the caller synchronises before (seg complete) and after
     __device__ void stage(float4 *s32, const double *seg, int nseg_, double kappa_)
     {
-        for (int g = threadIdx.x; g < NK - 1; g += kBlock)
-            s32[g] = make_float4((float)seg[4 * g], (float)seg[4 * g + 1], (float)seg[4 * g + 2], 0.0f);
+        if constexpr (PACKED) {
+            auto cs = [&](int g, int w) -> float { return g < NK - 1 ? (float)seg[4 * g + w] : (w == 0 ? 1.0f : 0.0f); };  // (padding: theta = 0)
+            for (int g = threadIdx.x; g < kH; g += kBlock) {
+                s32[g] = make_float4(cs(g, 0), cs(g + kH, 0), cs(g, 1), cs(g + kH, 1));
+                reinterpret_cast<float2 *>(s32 + kH)[g] = make_float2(cs(g, 2), cs(g + kH, 2));
+            }
+        } else {
+            for (int g = threadIdx.x; g < NK - 1; g += kBlock)
+                s32[g] = make_float4((float)seg[4 * g], (float)seg[4 * g + 1], (float)seg[4 * g + 2], 0.0f);
+        }
         seg32 = s32;
         nseg = nseg_;
         kappa = kappa_;
