@@ -23,6 +23,8 @@
 // very iteration.  Scheduling (two chains per lane, one parked in LDS, set-up when enough lanes wait) is
 // that of fast_kernel.
 #pragma once
+#include <type_traits>
+
 #include "gsss_fast.h"
 
 #ifndef GSSS_SCREEN_REGEN_THR
@@ -425,6 +427,10 @@ struct Curve32 {
                 prer[g] = rd[g];
             }
         }
+        // (a curve of exactly NK knots -- the usual case, 10 knots in the 10-knot build -- needs neither the per-segment "is
+        // this segment real" select nor a run-time test for the last segment: a copy of the loop for it, chosen per wavefront)
+        auto scan = [&](auto full_c) -> float {
+        constexpr bool kFull = decltype(full_c)::value;
         float best = -INFINITY;
 #pragma unroll
         for (int g = 0; g < kH; ++g) {
@@ -445,17 +451,22 @@ struct Curve32 {
                     const bool before_b = Ah >= (half ? cth.y : cth.x);  // t* <= theta_g
                     const bool inside = (Bh > 0.0f) & before_b;
                     float v = inside ? (half ? hr.y : hr.x) : ayh;
-                    if (seg == nseg - 1) {                               // (uniform) the last segment: b where the reference clips to it
+                    if (kFull ? seg == NK - 2 : seg == nseg - 1) {       // (uniform) the last segment: b where the reference clips to it
                         const bool at_a = (Bh < 0.0f) | ((Bh == 0.0f) & (Ah >= 0.0f));
                         v = fmaxf(v, (!before_b & !at_a) ? byh : -INFINITY);
                     }
-                    best = fmaxf(best, seg < nseg ? v : -INFINITY);
+                    best = fmaxf(best, (kFull || seg < nseg) ? v : -INFINITY);
                 }
             }
             ay = by;
             __builtin_amdgcn_sched_barrier(0);  // two segments at a time, as before (all of them side by side cost registers the callers do not have)
         }
         return fminf(best, 1.0f);
+        };
+        if constexpr (!PRELOAD) {  // (the two-wavefront builds, which preload, spill with a second copy of the loop)
+            if (nseg == NK - 1) return scan(std::true_type{});
+        }
+        return scan(std::false_type{});
       } else {
 
         float best = -INFINITY;
