@@ -41,6 +41,16 @@ namespace gsss {
 #ifndef GSSS_CS_WAVES_BIG
 #define GSSS_CS_WAVES_BIG 2
 #endif
+#ifndef GSSS_CS_PACKED_BELOW
+#define GSSS_CS_PACKED_BELOW 64  // lanes per chain below which the screen evaluates two segments per packed instruction (Curve32<.., PACKED>):
+                                 // every group size (sixteen lanes: packed with preloaded constants lost 1 %, packed without them and
+                                 // with the copy of the loop for full curves gains 1.4 %: d = 200 96.24 -> 94.9 ms)
+#endif
+#ifndef GSSS_CS_PRELOAD_Q
+#define GSSS_CS_PRELOAD_Q 2  // component quads per lane from which the try evaluation reads all segment constants in one go -- in the
+                             // sixteen-lane builds only: the four- and eight-lane ones evaluate segments in pairs and take the copy of the loop
+                             // for full curves instead, which preloading would make spill (round 4: d = 24 27.79 -> 26.58 ms, d = 50 33.90 -> 32.62)
+#endif
 #ifndef GSSS_CS_KNOT_PIPE
 #define GSSS_CS_KNOT_PIPE 1  // knot rows read from LDS one row ahead of their products (more than four components per lane)
 #endif
@@ -180,7 +190,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         sg[4 * i + 3] = 0.0;
     }
     __syncthreads();
-    Curve32<NK, (L < 16)> c32;
+    Curve32<NK, (L < GSSS_CS_PACKED_BELOW)> c32;
     c32.stage(reinterpret_cast<float4 *>(sg + 4 * (NK - 1)), sg, k - 1, tb.kappa);
     double *scr = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (threadIdx.x / L);
     double *ring = scr + 2;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         const double *knots = lds + opaque;
         Scalar scl = sc;
         scl.seg = knots + (size_t)NK * DPAD;
-        Curve32<NK, (L < 16)> c32s = c32;
+        Curve32<NK, (L < GSSS_CS_PACKED_BELOW)> c32s = c32;
         c32s.seg32 = reinterpret_cast<const float4 *>(knots + (size_t)NK * DPAD + 4 * (NK - 1));
         // ---------------- draws of the step
         double u[N], u_thr, u_th0;
@@ -340,7 +350,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
         for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
         // ---------------- a_r . u = (a_r . w) / |w|, a_r . x; single-precision pack; the doubles parked for decide()
         const bool refresh = !kRecur || s == 0 || ((step0 + (uint64_t)s) % kCoefRefresh) == 0;
-        float q[Curve32<NK, (L < 16)>::kFloats];
+        float q[Curve32<NK, (L < GSSS_CS_PACKED_BELOW)>::kFloats];
         {
             double pw = 0.0;
 #pragma unroll
@@ -525,7 +535,7 @@ __global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_
             const bool mine = !done && g < valid && t_base + g < max_tries;
             // (Q >= 2: two wavefronts per SIMD and registers to spare -- the segments' constants are read from LDS in one go, one
             // round trip per evaluation instead of one per segment: 38.3 -> 37.0 ms at d = 50, 105.4 -> 103.8 at d = 200)
-            const float my_b = c32s.template best32<(Q >= 2)>(q, c32f, s32);
+            const float my_b = c32s.template best32<(Q >= GSSS_CS_PRELOAD_Q && L >= GSSS_CS_PACKED_BELOW)>(q, c32f, s32);
             const float gap = my_b - q[2 * NK];
             int verdict = mine ? (gap < -q[2 * NK + 1] ? -1 : (gap > q[2 * NK + 1] ? 1 : 0)) : -1;
             // first try of the group that is not certainly rejected; an undecided one is decided in double precision by its lane

@@ -400,8 +400,8 @@ struct Curve32 {
     // vector instructions a segment, and the 2 NK products of a.y = c a.x + s a.u two at a time.  The constants rest in LDS
     // pair-major: seg32[g] = (cos_g, cos_{g+H}, sin_g, sin_{g+H}), then H pairs (1 / sin_g, 1 / sin_{g+H}).
     // Measured (profiles/r04_ab_packed_segments.log, ms per 10^8 chain-steps): d = 10 20.70 -> 20.27, d = 24 28.24 -> 27.68, d = 50
-    // 34.00 -> 33.92, d = 200 96.66 -> 97.78: PACKED for the four- and eight-lane groups, not for sixteen (nor the d = 3 lane kernel,
-    // unmeasured).
+    // 34.00 -> 33.92; with the copy of the loop for full curves below (and no preloaded constants): d = 10 19.2, d = 24 26.6, d = 50
+    // 32.6, d = 200 96.2 -> 94.9.  PACKED in every group kernel; the d = 3 lane kernel (ScreenCurve, unmeasured) keeps the scalar loop.
     static constexpr int kH = NK / 2;  // segments per half (NK = 10: 0..4 | 5..9, the tenth a padding one; NK = 17: 0..7 | 8..15)
     static_assert(6 * kH <= 4 * (NK - 1), "the pair-major constants fit where the per-segment ones were");
     typedef float f2 __attribute__((ext_vector_type(2)));
