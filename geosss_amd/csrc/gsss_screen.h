@@ -231,6 +231,7 @@ struct ScreenBingham : FastBingham<D> {
     static constexpr int kCoef32Floats = 6;
     static constexpr int kParkSkip = 0, kMinWaves = D > 10 ? 2 : 1, kTradeMin = 1;
     static constexpr bool kCompact = false, kRegenThr = false, kStageRows = true;
+    static constexpr bool kPreferOne = D != 6;  // the one-chain-per-lane build at any ensemble size (do_screened_run)
     static constexpr int kNumpyWaves = D >= 7 ? 2 : 3;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
@@ -304,6 +305,7 @@ struct ScreenBinghamDiag {
     static constexpr int kCoef32Floats = 4;  // q0 = -log U, q1 = qxu, q2 = (quu - qxx) - log U | margin
     static constexpr int kParkSkip = 0, kMinWaves = D >= 14 ? 2 : (D >= 9 ? 3 : 1), kTradeMin = 1;  // (d >= 14 spills at three)
     static constexpr bool kCompact = true, kRegenThr = true, kStageRows = true;
+    static constexpr bool kPreferOne = D >= 5;  // the one-chain-per-lane build at any ensemble size (do_screened_run)
     static constexpr int kNumpyWaves = 3;
     const double *a;  // LDS [D]: the diagonal of A
     struct Coef {
@@ -792,7 +794,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
     // This workgroup's work: its chunk of chains for the whole launch -- or, in the sliced partial round of a launch
     // (plan_partial_round, gsss_device.h), the (chunk, step slice) of the ticket it draws.  A chain's step count runs over the
     // launch's steps [s_begin, n_steps): counters of the stream and retained rows need nothing else.
-    constexpr int kChunk = (screen_parks<D, TP>() && !NUMPY) ? 2 * kBlock : kBlock;  // chains per workgroup
+    constexpr int kChunk = (screen_parks<D, TP>() && !NUMPY && !STAGE) ? 2 * kBlock : kBlock;  // chains per workgroup
     __shared__ uint32_t sched_word[4];
     const bool sliced = a.sched != nullptr && (int32_t)blockIdx.x >= a.sched_first;
     uint32_t chunk = blockIdx.x;
@@ -808,7 +810,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
     const double rcp_thin = 1.0 / (double)thin;  // (compact chains: the retained row follows from the step count)
     const int32_t max_tries = a.max_tries < (1 << 25) ? a.max_tries : (1 << 25) - 1;  // t shares a word with the flags
     constexpr uint32_t kTryBase = 1u + (uint32_t)((D + 3) / 4);
-    constexpr bool kPark = screen_parks<D, TP>() && !NUMPY;  // (a generator per chain: one chain per lane)
+    constexpr bool kPark = screen_parks<D, TP>() && !NUMPY && !STAGE;  // (NUMPY: a generator per chain; STAGE: built for one chain per lane)
     constexpr int kPerBlock = kPark ? 2 * kBlock : kBlock;
     // (one_per_lane: kBlock chains per workgroup, the lane's second slot stays empty -- a chain id past the ensemble)
     const int32_t id0 = (int32_t)chunk * (a.one_per_lane ? kBlock : kPerBlock) + (int32_t)threadIdx.x;
@@ -1300,24 +1302,34 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
                 one_per_lane = per_cu_one > per_cu;
         }
     }
+    // Bingham targets: the one-chain-per-lane BUILD (below) is ahead of two chains per lane at 10^6 chains too for most shapes
+    // (tools/bench_pure_one.py, profiles/r04_bingham_pure_one.log: eigenbasis d = 5 .. 7, 9, 10 +3 .. 5 %, dense d = 3 .. 5, 7 +4 %,
+    // d = 8 +22 %, d = 10 +8 %; behind at eigenbasis d = 4 (-2 %) and dense d = 6 (-10 %: 170 registers, two wavefronts): TP::kPreferOne
+    if constexpr (!REPLAY && TP::kStageRows && D <= 10) {
+        if (TP::kPreferOne && !(env_one && env_one[0] == '0') && rb.stats == nullptr) one_per_lane = true;
+    }
     bool stage_rows = false;
     if (one_per_lane) {
         per_block = kBlock;
         lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
-        // chain-major retained rows that are not whole sectors are held back in that LDS until their run is (screened_kernel<.., STAGE>)
-        if constexpr (!REPLAY && TP::kStageRows && D <= 10 && D % 4 != 0) {
-            constexpr int kStageP = (D % 2 == 0) ? 2 : 4;
-            const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
-            if (rb.samples != nullptr && rb.keep_rows > 0 && rb.stats == nullptr && !(env_stage && env_stage[0] == '0')) {
-                // ... unless that LDS would cost a resident workgroup (bytes at 0.3 % of the HBM peak are not worth a wavefront)
-                auto kern_staged = screened_kernel<D, TP, false, false, true>;
-                const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
-                if (resident_workgroups(reinterpret_cast<const void *>(kern_staged), lds_staged) >= resident_workgroups(reinterpret_cast<const void *>(kern), lds)) {
-                    if (lds_staged > 48 * 1024)
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged);
-                    stage_rows = true;
-                    lds = lds_staged;
-                    kern = kern_staged;
+        // Bingham targets: a build of the kernel for ONE chain per lane (screened_kernel<.., STAGE>: no code for a parked chain --
+        // 154 instead of 143 registers at d = 10, but nothing of the trade logic in the loop: compact d = 10, 10^6 chains, 39.3 ->
+        // 36.85 ms, ahead of two chains per lane at 37.45), which also holds chain-major retained rows that are not whole sectors
+        // back in LDS until their run is (kStageP > 1; only where that LDS costs no resident workgroup)
+        if constexpr (!REPLAY && TP::kStageRows && D <= 10) {
+            if (rb.stats == nullptr) {
+                auto kern_one = screened_kernel<D, TP, false, false, true>;
+                kern = kern_one;
+                constexpr int kStageP = (D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+                const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
+                if (kStageP > 1 && rb.samples != nullptr && rb.keep_rows > 0 && !(env_stage && env_stage[0] == '0')) {
+                    const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
+                    if (resident_workgroups(reinterpret_cast<const void *>(kern_one), lds_staged) >= resident_workgroups(reinterpret_cast<const void *>(kern_one), lds)) {
+                        if (lds_staged > 48 * 1024)
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern_one), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged);
+                        stage_rows = true;
+                        lds = lds_staged;
+                    }
                 }
             }
         }
