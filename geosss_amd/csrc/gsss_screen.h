@@ -27,6 +27,12 @@
 
 #include "gsss_fast.h"
 
+#ifndef GSSS_VMF_ONE_BUILD
+#define GSSS_VMF_ONE_BUILD 1  // (0: without the one-chain-per-lane build of the K = 7 .. 10 mixtures, A/B)
+#endif
+#ifndef GSSS_VMF_ONE_ALL
+#define GSSS_VMF_ONE_ALL 0  // (measurement: build it for every bucket; GSSS_ONE_PER_LANE=2 then runs it)
+#endif
 #ifndef GSSS_SCREEN_REGEN_THR
 #define GSSS_SCREEN_REGEN_THR 1  // (A/B: 0 parks the threshold uniform of the S^2 mixtures as round 2 did)
 #endif
@@ -96,7 +102,15 @@ struct ScreenVmf : FastVmf<D, KC> {
     // with the cheap swaps of K <= 5 and of the Bingham target waiting costs more than it saves (27.7 -> 28.3 / 28.6 ms at 12 / 24).
     static constexpr int kTradeMin = KC >= 6 ? 24 : 1;
     static constexpr bool kCompact = false;
-    static constexpr bool kStageRows = false;  // (rows held back in LDS, screened_kernel<.., STAGE>: built for the Bingham targets, where it was measured)
+    // The one-chain-per-lane BUILD (screened_kernel<.., STAGE>: no code for a parked chain; do_screened_run) at any ensemble size
+    // where it was measured ahead at 10^6 chains (tools/bench_vmf_pure_one.py, profiles/r04_vmf_pure_one.log): bucket 10 at every
+    // d (+6 .. 11 %; cfg5, S^2 K = 10 kappa = 500: 48.9 -> 46.8 ms), bucket 6 up to d = 8 (+4 .. 10 %), bucket 16 up to d = 5 (+7 %),
+    // bucket 4 on S^2 (+7 %), bucket 3 at d = 4 (+4.5 %).  The README kernel (S^2, K = 3) stays with two chains per lane (24.1
+    // against 24.7 ms); everything else is within 1 % either way and keeps the old rule.
+    static constexpr bool kOneAhead = KC == 10 || (KC == 6 && D <= 8) || (KC == 16 && D <= 5) || (KC == 4 && D == 3) || (KC == 3 && D == 4);
+    static constexpr bool kStageRows = GSSS_VMF_ONE_BUILD && (kOneAhead || GSSS_VMF_ONE_ALL);
+    static constexpr bool kHoldRows = false;  // ... without the rows held back in LDS (registers)
+    static constexpr bool kPreferOne = GSSS_VMF_ONE_BUILD && kOneAhead;
     static constexpr int kNumpyWaves = (KC >= 10 || (D >= 9 && KC >= 6)) ? 2 : ((D <= 4 && KC <= 3) ? 4 : 3);  // wavefronts per SIMD of the numpy-stream build: without scratch, but for the smallest
                                                    // shapes, where a fourth wavefront is worth 12-20 spilled bytes (README target 40.9 -> 38.7 ms)
     // S^2, K <= 3 (the README target, BASELINE cfg2): the threshold uniform is not parked -- an undecided try draws it again
@@ -232,6 +246,7 @@ struct ScreenBingham : FastBingham<D> {
     static constexpr int kParkSkip = 0, kMinWaves = D > 10 ? 2 : 1, kTradeMin = 1;
     static constexpr bool kCompact = false, kRegenThr = false, kStageRows = true;
     static constexpr bool kPreferOne = D != 6;  // the one-chain-per-lane build at any ensemble size (do_screened_run)
+    static constexpr bool kHoldRows = true;
     static constexpr int kNumpyWaves = D >= 7 ? 2 : 3;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
@@ -306,6 +321,7 @@ struct ScreenBinghamDiag {
     static constexpr int kParkSkip = 0, kMinWaves = D >= 14 ? 2 : (D >= 9 ? 3 : 1), kTradeMin = 1;  // (d >= 14 spills at three)
     static constexpr bool kCompact = true, kRegenThr = true, kStageRows = true;
     static constexpr bool kPreferOne = D >= 5;  // the one-chain-per-lane build at any ensemble size (do_screened_run)
+    static constexpr bool kHoldRows = true;
     static constexpr int kNumpyWaves = 3;
     const double *a;  // LDS [D]: the diagonal of A
     struct Coef {
@@ -595,7 +611,7 @@ struct ScreenCurve : FastCurve<D, NK> {
     using Coef = typename Base::Coef;
     static constexpr int kCoef32Floats = 2 * NK + 2;  // ax | au | thr / kappa | margin
     static constexpr int kParkSkip = 0, kMinWaves = 1, kTradeMin = 1;
-    static constexpr bool kCompact = false, kRegenThr = false, kStageRows = false;
+    static constexpr bool kCompact = false, kRegenThr = false, kStageRows = false, kHoldRows = false;
     static constexpr int kNumpyWaves = 2;
     __device__ __forceinline__ void retail(float (&)[kCoef32Floats]) const {}
     __device__ __forceinline__ void refill(const double (&)[D], const double (&)[D], float (&)[kCoef32Floats]) const {}
@@ -785,7 +801,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
     // a sector boundary and stores the run at once (a.stage_rows, set by do_screened_run; same bytes in the same places).
     // A build of its own (STAGE; do_screened_run picks it for Bingham targets at d <= 10 when rows are kept that way): inside the
     // plain kernels the extra state cost the two-chains-per-lane launches of the bench 0.6 % for nothing (measured).
-    constexpr int kStageP = (!STAGE || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+    constexpr int kStageP = (!STAGE || !TP::kHoldRows || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
     double *stage = reinterpret_cast<double *>(park);  // [kStageP - 1][D][kBlock] doubles (nothing is parked in that mode)
     int32_t n_staged = 0;
     __syncthreads();
@@ -1320,7 +1336,7 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
             if (rb.stats == nullptr) {
                 auto kern_one = screened_kernel<D, TP, false, false, true>;
                 kern = kern_one;
-                constexpr int kStageP = (D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
+                constexpr int kStageP = (!TP::kHoldRows || D % 4 == 0) ? 1 : ((D % 2 == 0) ? 2 : 4);
                 const char *env_stage = getenv("GSSS_STAGE_ROWS");  // "0": off (A/B)
                 if (kStageP > 1 && rb.samples != nullptr && rb.keep_rows > 0 && !(env_stage && env_stage[0] == '0')) {
                     const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
