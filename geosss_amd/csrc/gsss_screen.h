@@ -1146,7 +1146,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
     auto flush = [&]() {
         const int32_t c = chain_id();
         if (c >= n) return;
-        if (kStageP > 1 && n_staged > 0) unstage(&a.samples[sample_index(a, cur.row, 0, D, c)]);  // (the chain's next row starts there)
+        // (the chain's next row starts behind them: row steps_done / thin -- compact chains derive cur.row from the step count at
+        // every move, where it names the LAST kept row until the next one is due)
+        if (kStageP > 1 && n_staged > 0) unstage(&a.samples[sample_index(a, cur.steps_done / thin, 0, D, c)]);
         if constexpr (NUMPY) nd.finish(a, c, true);
 #pragma unroll
         for (int j = 0; j < D; ++j) put_out(&a.state[(size_t)j * n + c], cur.x[j]);
@@ -1318,9 +1320,11 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
                 one_per_lane = per_cu_one > per_cu;
         }
     }
-    // Bingham targets: the one-chain-per-lane BUILD (below) is ahead of two chains per lane at 10^6 chains too for most shapes
-    // (tools/bench_pure_one.py, profiles/r04_bingham_pure_one.log: eigenbasis d = 5 .. 7, 9, 10 +3 .. 5 %, dense d = 3 .. 5, 7 +4 %,
-    // d = 8 +22 %, d = 10 +8 %; behind at eigenbasis d = 4 (-2 %) and dense d = 6 (-10 %: 170 registers, two wavefronts): TP::kPreferOne
+    // The one-chain-per-lane BUILD (below) is ahead of two chains per lane at 10^6 chains too for most shapes that have it
+    // (TP::kStageRows): TP::kPreferOne says where.  Bingham targets (tools/bench_pure_one.py, profiles/r04_bingham_pure_one.log):
+    // eigenbasis d = 5 .. 7, 9, 10 +3 .. 5 %, dense d = 3 .. 5, 7 +4 %, d = 8 +22 %, d = 10 +8 %; behind at eigenbasis d = 4 (-2 %) and
+    // dense d = 6 (-10 %: 170 registers, two wavefronts).  Mixtures (tools/bench_vmf_pure_one.py, profiles/r04_vmf_pure_one.log):
+    // ScreenVmf::kOneAhead.
     if constexpr (!REPLAY && TP::kStageRows && D <= 10) {
         if (TP::kPreferOne && !(env_one && env_one[0] == '0') && rb.stats == nullptr) one_per_lane = true;
     }
@@ -1328,10 +1332,10 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     if (one_per_lane) {
         per_block = kBlock;
         lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
-        // Bingham targets: a build of the kernel for ONE chain per lane (screened_kernel<.., STAGE>: no code for a parked chain --
-        // 154 instead of 143 registers at d = 10, but nothing of the trade logic in the loop: compact d = 10, 10^6 chains, 39.3 ->
-        // 36.85 ms, ahead of two chains per lane at 37.45), which also holds chain-major retained rows that are not whole sectors
-        // back in LDS until their run is (kStageP > 1; only where that LDS costs no resident workgroup)
+        // A build of the kernel for ONE chain per lane (screened_kernel<.., STAGE>: no code for a parked chain -- Bingham d = 10: 154
+        // instead of 143 registers, but nothing of the trade logic in the loop: 10^6 chains, 39.3 -> 36.85 ms, ahead of two chains
+        // per lane at 37.45), which for the Bingham targets (TP::kHoldRows) also holds chain-major retained rows that are not whole
+        // sectors back in LDS until their run is (kStageP > 1; only where that LDS costs no resident workgroup)
         if constexpr (!REPLAY && TP::kStageRows && D <= 10) {
             if (rb.stats == nullptr) {
                 auto kern_one = screened_kernel<D, TP, false, false, true>;

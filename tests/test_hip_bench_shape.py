@@ -52,8 +52,9 @@ def _check_blocks(gs, oracle, workload, n, blocks, kernel_prefix, chains_per_chu
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed)
     name = s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0, 1).decode()
     assert s.mode == "fast" and name.startswith(kernel_prefix), name
-    kept = torch.empty((S // thin, d, n), dtype=torch.float64, device="cuda")
-    s.advance(S, thin=thin, out=kept)
+    layout = bench.pick_layout("auto", name, d, thin)                 # the layout of the kept rows bench.py's line is timed on
+    kept, kw = bench.kept_buffer(torch, layout, n, S, thin, d)
+    s.advance(S, thin=thin, out=kept, **kw)
     torch.cuda.synchronize()
     grid, slice_steps, frac = _last_launch(gs)
     n_chunks = -(-n // chains_per_chunk)
@@ -71,14 +72,14 @@ def _check_blocks(gs, oracle, workload, n, blocks, kernel_prefix, chains_per_chu
         ids = slice(lo, lo + m)
         want = oracle.run(tgt, x0_host[ids], S, seed=seed, chain_offset=lo, thin=thin, n_threads=16)
         assert np.all(want["err"] == 0)
-        got_rows = kept[:, :, ids].permute(2, 0, 1).cpu().numpy()   # (chains, rows, d)
+        got_rows = (kept[ids] if layout == "chains" else kept[:, :, ids].permute(2, 0, 1)).cpu().numpy()   # (chains, rows, d)
         assert np.array_equal(s._n_tries[ids].cpu().numpy(), want["n_tries"]), kind
         assert np.array_equal(s._n_reject[ids].cpu().numpy(), want["n_reject"]), kind
         assert np.max(np.abs(got_rows - want["samples"])) < TOL, kind
         assert np.max(np.abs(s.state_device[:, ids].T.cpu().numpy() - want["state"])) < TOL, kind
         n_checked += m
         where.append(kind)
-    return n_checked, where, frac
+    return n_checked, where, frac, layout
 
 
 def test_headline_launch_matches_oracle(gs, oracle, monkeypatch):
@@ -94,7 +95,7 @@ def test_headline_launch_matches_oracle(gs, oracle, monkeypatch):
                 ("sliced chunks, far end", (n_chunks - 3) * per - 64, 640),
                 ("ragged last chunk and its neighbour", 1_000_000 - 800, 800)]
 
-    n_checked, where, frac = _check_blocks(gs, oracle, "vmfmix_readme", 1_000_000, blocks, "screened_kernel<3, ScreenVmf<3, 3>>", per,
+    n_checked, where, frac, _ = _check_blocks(gs, oracle, "vmfmix_readme", 1_000_000, blocks, "screened_kernel<3, ScreenVmf<3, 3>>", per,
                                            (0.2, 0.5), monkeypatch)
     assert n_checked >= 4000 and len(where) == 6
 
@@ -106,5 +107,37 @@ def test_curve_d50_launch_matches_oracle(gs, oracle, monkeypatch):
     def blocks(first, n_chunks):
         return [("first chunks", 0, 160), ("middle", (n_chunks // 2) * per - 30, 160), ("ragged last chunk and its neighbours", 100_000 - 160, 160)]
 
-    n_checked, where, frac = _check_blocks(gs, oracle, "curve_d50", 100_000, blocks, "curvespec_kernel<4, 4, 10", per, (1.0, 1.0), monkeypatch)
+    n_checked, where, frac, _ = _check_blocks(gs, oracle, "curve_d50", 100_000, blocks, "curvespec_kernel<4, 4, 10", per, (1.0, 1.0), monkeypatch)
     assert n_checked == 480
+
+
+@pytest.mark.parametrize("workload,kernel,per,m", [("curve_d10", "curvespec_kernel<4, 1, 10", 64, 320), ("curve_d24", "curvespec_kernel<4, 2, 10", 64, 200),
+                                                    ("curve_d200", "curvespec_kernel<16, 4, 10", 16, 48)])
+def test_curve_launches_match_oracle(gs, oracle, monkeypatch, workload, kernel, per, m):
+    """cfg4's other points at their full size (10^5 chains x 1000 transitions, every chunk sliced): three- and two-wavefront builds,
+    four- and sixteen-lane groups, the packed segment evaluation with the full-curve copy of its loop."""
+
+    def blocks(first, n_chunks):
+        return [("first chunks", 0, m), ("middle", (n_chunks // 2) * per - per // 2, m), ("ragged last chunk and its neighbours", 100_000 - m, m)]
+
+    n_checked, where, frac, _ = _check_blocks(gs, oracle, workload, 100_000, blocks, kernel, per, (1.0, 1.0), monkeypatch)
+    assert n_checked == 3 * m
+
+
+@pytest.mark.parametrize("workload,kernel,want_layout", [("bingham_d10", "screened_kernel<10, ScreenBinghamDiag<10>>", "chains"),
+                                                          ("vmfmix_k10_kappa500", "screened_kernel<3, ScreenVmf<3, 10>>", "components")])
+def test_one_chain_per_lane_launches_match_oracle(gs, oracle, monkeypatch, workload, kernel, want_layout):
+    """cfg3 / cfg5 as bench.py launches them: 10^6 chains x 1000 transitions in the kernels' one-chain-per-lane BUILD (256-chain
+    workgroups, no parked chain; round 4), the last workgroups sliced; cfg3 writes the reference's (chains, draws, dims) rows, held
+    back in LDS until a run of them ends on a 32-byte sector."""
+    per = 256
+
+    def blocks(first, n_chunks):
+        return [("first workgroups", 0, 384),
+                ("an unsliced chunk in the middle", (first // 2) * per - 64, 384),
+                ("across the whole-launch | sliced boundary", first * per - 192, 384),
+                ("sliced chunks", (first + (n_chunks - first) // 2) * per - 100, 384),
+                ("ragged last chunk and its neighbour", 1_000_000 - 400, 400)]
+
+    n_checked, where, frac, layout = _check_blocks(gs, oracle, workload, 1_000_000, blocks, kernel, per, (0.005, 0.2), monkeypatch)
+    assert layout == want_layout and n_checked >= 1900 and len(where) == 5

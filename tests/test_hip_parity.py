@@ -1053,7 +1053,8 @@ def test_long_launch_gets_longer_slices(gs, monkeypatch):
     assert int((out["whole"][4] != 0).sum()) == 0
 
 
-@pytest.mark.parametrize("name", ["bingham_d10_vmax30", "bingham_d5_dense", "binghamfisher_d5", "binghamfisher_d6", "vmfmix_readme"])
+@pytest.mark.parametrize("name", ["bingham_d10_vmax30", "bingham_d5_dense", "binghamfisher_d5", "binghamfisher_d6", "vmfmix_readme",
+                                  "wide:bingham_diag:3", "wide:bingham:7", "wide:bingham_diag:9", "wide:bingham:9", "wide:bingham_diag:8"])
 def test_rows_held_back_in_lds_land_where_they_belong(gs, name, monkeypatch):
     """One chain per lane, (chains, draws, dims) output, Bingham targets at d <= 10 (the mixture runs the plain kernel either way:
     the control): rows of 8 d bytes that do not end on a 32-byte sector are held back in LDS
@@ -1062,9 +1063,12 @@ def test_rows_held_back_in_lds_land_where_they_belong(gs, name, monkeypatch):
     starts at row 1), thinning, runs of rows split over launches (the Python classes cap a launch at 4096 steps) and chains that
     stop early (max_tries)."""
     import torch
-    z = golden(f"traj_{name}.npz")
-    pdf = product_target(z)
-    d = len(z["x0"])
+    if name.startswith("wide:"):                             # (every row size modulo a sector: d = 3, 7, 9 wait for four rows, d = 8 for none)
+        pdf, d = _wide_target(gs, name)
+    else:
+        z = golden(f"traj_{name}.npz")
+        pdf = product_target(z)
+        d = len(z["x0"])
     n = 30_000                                               # one chain per lane at this size
     x0 = gs.sample_sphere_device(d - 1, n, seed=61).T
     out = {}
@@ -1078,12 +1082,16 @@ def test_rows_held_back_in_lds_land_where_they_belong(gs, name, monkeypatch):
         a = s.sample(23, burnin=3, thin=7, as_tensor=True)                # rows 1 .. 22 of a 23-row run, one launch
         b = s.sample(12, thin=500, as_tensor=True)                        # 5500 steps: two launches, 8 + 3 rows
         buf = torch.zeros((n, 9, d), dtype=torch.float64, device="cuda")  # an odd run length: chains start on either sector phase
-        s.advance(8 * 3, thin=3, out=buf, chain_major=True, row0=1)
+        s.advance(8 * 3 + 2, thin=3, out=buf, chain_major=True, row0=1)   # ... and the launch goes on for two steps behind its last row
+        buf2 = torch.zeros((n, 3, d), dtype=torch.float64, device="cuda")
+        s.advance(19, thin=5, out=buf2, chain_major=True)                 # rows 0 .. 2, the last one held back when the launch ends 4 steps later
         t = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=14, mode="fast", placement="packed", max_tries=14)
         c = torch.zeros((n, 40, d), dtype=torch.float64, device="cuda")
         t.advance(40, thin=1, out=c, chain_major=True)                    # some chains stop early: their held-back rows still go out
-        out[label] = (a.clone(), b.clone(), buf.clone(), c.clone(), t._err.clone(), s.state_device.clone())
-    for i in range(6):
+        out[label] = (a.clone(), b.clone(), buf.clone(), c.clone(), t._err.clone(), s.state_device.clone(), buf2.clone())
+    for i in range(7):
         assert torch.equal(out["staged"][i], out["plain"][i]), i
-    assert 0 < int((out["plain"][4] != 0).sum()) < n
+    assert float(out["staged"][6].abs().min()) > 0.0
+    stopped = int((out["plain"][4] != 0).sum())
+    assert stopped < n and (stopped > 0 or name.startswith("wide:"))   # (the reference's targets: some chains do stop at 14 tries)
     assert float(out["staged"][2][:, 0].abs().max()) == 0.0 and float(out["staged"][2][:, 1:].abs().min()) > 0.0  # row 0 untouched, rows 1 .. 8 written
