@@ -1,0 +1,178 @@
+"""Randomised differential test of the lane kernels' launch machinery.
+
+One chain per lane or two, the one-chain-per-lane BUILD (`screened_kernel<.., STAGE>`), rows held back in LDS until a run of them
+ends on a sector, a sliced last round of workgroups, chain-major or component-major retained rows, row offsets, launches that end
+between two kept rows, chains that stop at max_tries: each is a choice the library makes from the launch's shape, and none of them
+may change a bit.  Every case draws a target, an ensemble size around the chip's resident workgroups, step counts, thinning and an
+output layout at random (seeded), runs it as the library would and again with every one of those choices switched off
+(GSSS_ONE_PER_LANE=0, GSSS_STAGE_ROWS=0, GSSS_SLICE_STEPS=0: two chains per lane, plain stores, one workgroup per chunk for the
+whole launch), and compares states, retained rows, tries, rejections and error flags bitwise.  The plain configuration is the
+one the oracle tests of test_hip_parity.py hold to the reference's chains.  (geosss/mcmc.py:55-77, 382-401: `sample` keeps every
+thin-th state of every chain, whatever the launch shape.)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OFF = {"GSSS_ONE_PER_LANE": "0", "GSSS_STAGE_ROWS": "0", "GSSS_SLICE_STEPS": "0"}
+SEEN = {"cases": 0, "sliced": 0, "chain_major": 0, "bingham_chain_major_open_end": 0, "stopped_chains": 0}
+
+
+@pytest.fixture(scope="module")
+def gs():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import geosss_amd
+    geosss_amd._lib.require_device()
+    return geosss_amd
+
+
+def _target(gs, rng):
+    kind = rng.choice(["vmf", "bingham_diag", "bingham"])
+    d = int(rng.integers(3, 11))
+    if kind == "vmf":
+        k = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 13, 16]))
+        mu = float(rng.uniform(20.0, 90.0)) * gs.sample_sphere(d - 1, k, seed=int(rng.integers(1 << 30)))
+        return gs.MixtureModel([gs.VonMisesFisher(m) for m in mu], rng.uniform(0.5, 2.0, k)), d, f"vmf d={d} K={k}"
+    pdf = gs.random_bingham(d=d, vmax=float(rng.uniform(10.0, 40.0)), vmin=0.0, eigensystem=kind == "bingham_diag", seed=int(rng.integers(1 << 30)))
+    return pdf, d, f"{kind} d={d}"
+
+
+def _run(gs, torch, pdf, d, x0, cfg, env, monkeypatch):
+    for k in OFF:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cls = gs.RejectionSphericalSliceSampler if cfg["sampler"] == "reject" else gs.ShrinkageSphericalSliceSampler
+    s = cls(pdf, x0, seed=cfg["seed"], mode="fast", placement="packed", step_offset=cfg["step_offset"], max_tries=cfg["max_tries"])
+    name = s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0, 1).decode()
+    assert name.startswith("screened_kernel"), name
+    n = x0.shape[0]
+    outs, sliced = [], False
+    for n_steps, thin, row0 in cfg["launches"]:
+        rows = n_steps // thin
+        if cfg["chain_major"]:
+            buf = torch.zeros((n, rows + row0 + 1, d), dtype=torch.float64, device="cuda")
+            s.advance(n_steps, thin=thin, out=buf, chain_major=True, row0=row0)
+        else:
+            buf = torch.zeros((rows, d, n), dtype=torch.float64, device="cuda")
+            if rows > 0:
+                s.advance(n_steps, thin=thin, out=buf)
+            else:
+                s.advance(n_steps)
+        steps = C.c_int32(0)
+        s._lib.gsss_last_launch(None, C.byref(steps), None)
+        sliced = sliced or steps.value != 0
+        outs.append(buf)
+    torch.cuda.synchronize()
+    return dict(rows=outs, state=s.state_device.clone(), tries=s._n_tries.clone(), rej=s._n_reject.clone(), err=s._err.clone(), sliced=sliced, kernel=name)
+
+
+@pytest.mark.parametrize("case", range(96))
+def test_launch_choices_do_not_change_a_bit(gs, case, monkeypatch):
+    import torch
+    rng = np.random.default_rng(9000 + case)
+    pdf, d, what = _target(gs, rng)
+    # ensembles: small (one chain per lane by the size rule), around one round of resident workgroups + a few (a sliced partial
+    # round: 768 .. 1280 workgroups are resident, 256 or 512 chains each), ragged last chunks
+    size = rng.choice(["small", "mid", "round"])
+    n = {"small": int(rng.integers(300, 40_000)), "mid": int(rng.integers(100_000, 260_000)),
+         "round": int(rng.choice([512, 768, 1024, 1280])) * int(rng.choice([256, 512])) + int(rng.integers(1, 60)) * 256 - int(rng.integers(0, 255))}[size]
+    sampler = "reject" if rng.random() < 0.25 else "shrink"
+    launches = []
+    for _ in range(int(rng.integers(1, 4))):
+        thin = int(rng.choice([1, 2, 3, 7, 10, 50, 100, 129]))
+        n_steps = int(rng.integers(1, 5)) * 128 + int(rng.integers(0, 128)) if rng.random() < 0.6 else int(rng.integers(1, 200))
+        thin = max(thin, -(-n_steps // 40))                              # (at most 40 rows a launch: the buffers of 6 x 10^5 chains stay small)
+        launches.append((n_steps, thin, int(rng.integers(0, 3))))
+    cfg = dict(sampler=sampler, seed=int(rng.integers(1 << 30)), step_offset=int(rng.integers(0, 1000)), launches=launches,
+               chain_major=bool(rng.random() < 0.6), max_tries=(1 << 20) if sampler == "reject" or rng.random() < 0.6 else int(rng.integers(8, 30)))
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+    got = _run(gs, torch, pdf, d, x0, cfg, {}, monkeypatch)
+    ref = _run(gs, torch, pdf, d, x0, cfg, OFF, monkeypatch)
+    info = (what, n, cfg, got["kernel"], "sliced" if got["sliced"] else "unsliced")
+    assert not ref["sliced"], info
+    for key in ("state", "tries", "rej", "err"):
+        assert torch.equal(got[key], ref[key]), (key, info)
+    for i, (a, b) in enumerate(zip(got["rows"], ref["rows"])):
+        assert torch.equal(a, b), (f"rows of launch {i}", info)
+    SEEN["cases"] += 1
+    SEEN["sliced"] += int(got["sliced"])
+    SEEN["chain_major"] += int(cfg["chain_major"])
+    SEEN["bingham_chain_major_open_end"] += int(cfg["chain_major"] and what.startswith("bingham") and any(m % t for m, t, _ in launches))
+    SEEN["stopped_chains"] += int(bool((ref["err"] != 0).any()))
+
+
+def test_the_cases_covered_the_choices():
+    """(runs behind the cases above) the draw of cases did reach what this file is about"""
+    if SEEN["cases"] < 96:
+        pytest.skip("not every case ran in this process")
+    assert SEEN["sliced"] >= 10 and SEEN["chain_major"] >= 30 and SEEN["bingham_chain_major_open_end"] >= 10 and SEEN["stopped_chains"] >= 10, SEEN
+
+
+CURVE_SEEN = {"cases": 0, "sliced": 0}
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_group_kernel_slicing_does_not_change_a_bit(gs, case, monkeypatch):
+    """The group-speculative curve kernels cut EVERY chunk of a launch into step slices once the chunks outnumber the resident
+    workgroups: any dimension 4 .. 256 (lane groups of 4, 8, 16; one to four component quads a lane), 2 .. 17 knots, ragged
+    ensembles, several launches (slices restart at the launch's global step), either layout of the retained rows -- against one
+    workgroup per chunk (GSSS_SLICE_STEPS=0), bitwise."""
+    import torch
+    rng = np.random.default_rng(7000 + case)
+    d = int(rng.choice([4, 5, 8, 10, 13, 16, 17, 24, 33, 50, 64, 65, 100, 128, 129, 200, 256]))
+    k = int(rng.choice([2, 3, 7, 10, 10, 10, 12, 16 if d <= 64 else 17])) if d <= 48 or d > 64 else int(rng.choice([2, 5, 10, 10]))
+    knots = gs.brownian_curve(k, d, 0.5, seed=int(rng.integers(1 << 30)))
+    pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), float(rng.choice([100.0, 300.0, 800.0])))
+    per = 64 if d <= 64 else (32 if d <= 128 and k <= 10 else 16)
+    n = int(rng.integers(600, 1400)) * per - int(rng.integers(0, per)) if rng.random() < 0.7 else int(rng.integers(2000, 20_000))
+    sampler = "reject" if rng.random() < 0.2 else "shrink"
+    launches = [(int(rng.integers(2, 5)) * 128 + int(rng.integers(0, 128)), int(rng.choice([1, 5, 64, 100])), 0) for _ in range(int(rng.integers(1, 3)))]
+    launches = [(m, max(t, -(-m // 12)), r) for m, t, r in launches]
+    cfg = dict(sampler=sampler, seed=int(rng.integers(1 << 30)), step_offset=int(rng.integers(0, 1000)), launches=launches,
+               chain_major=bool(rng.random() < 0.4), max_tries=(1 << 20) if sampler == "reject" or rng.random() < 0.7 else int(rng.integers(12, 40)))
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+
+    def run(env):
+        monkeypatch.delenv("GSSS_SLICE_STEPS", raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+        s = cls(pdf, x0, seed=cfg["seed"], mode="fast", placement="packed", step_offset=cfg["step_offset"], max_tries=cfg["max_tries"])
+        name = s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0, 1).decode()
+        assert name.startswith("curvespec_kernel"), name
+        outs, sliced = [], False
+        for n_steps, thin, row0 in launches:
+            rows = n_steps // thin
+            if cfg["chain_major"]:
+                buf = torch.zeros((n, rows + 1, d), dtype=torch.float64, device="cuda")
+                s.advance(n_steps, thin=thin, out=buf, chain_major=True, row0=row0)
+            else:                                             # (zeroed: a chain that stops keeps no further rows, and advance() hands out torch.empty)
+                buf = torch.zeros((rows, d, n), dtype=torch.float64, device="cuda")
+                s.advance(n_steps, thin=thin, out=buf)
+            steps = C.c_int32(0)
+            s._lib.gsss_last_launch(None, C.byref(steps), None)
+            sliced = sliced or steps.value != 0
+            outs.append(buf.clone())
+        torch.cuda.synchronize()
+        return outs, s.state_device.clone(), s._n_tries.clone(), s._n_reject.clone(), s._err.clone(), sliced, name
+
+    got, ref = run({}), run({"GSSS_SLICE_STEPS": "0"})
+    info = (d, k, n, cfg, got[6], "sliced" if got[5] else "unsliced")
+    assert not ref[5], info
+    for i in range(1, 5):
+        assert torch.equal(got[i], ref[i]), (i, info)
+    for a, b in zip(got[0], ref[0]):
+        assert torch.equal(a, b), ("rows", info)
+    CURVE_SEEN["cases"] += 1
+    CURVE_SEEN["sliced"] += int(got[5])
+
+
+def test_the_curve_cases_were_sliced():
+    if CURVE_SEEN["cases"] < 40:
+        pytest.skip("not every case ran in this process")
+    assert CURVE_SEEN["sliced"] >= 12, CURVE_SEEN
