@@ -176,3 +176,90 @@ def test_the_curve_cases_were_sliced():
     if CURVE_SEEN["cases"] < 40:
         pytest.skip("not every case ran in this process")
     assert CURVE_SEEN["sliced"] >= 12, CURVE_SEEN
+
+
+def _any_target(gs, rng, dims):
+    kind = rng.choice(["vmf", "bingham_diag", "bingham"])
+    d = int(rng.choice(dims))
+    if kind == "vmf":
+        k = int(rng.choice([1, 2, 3, 5, 6, 9, 10]))
+        mu = float(rng.uniform(20.0, 90.0)) * gs.sample_sphere(d - 1, k, seed=int(rng.integers(1 << 30)))
+        return gs.MixtureModel([gs.VonMisesFisher(m) for m in mu], rng.uniform(0.5, 2.0, k)), d, f"vmf d={d} K={k}"
+    pdf = gs.random_bingham(d=d, vmax=float(rng.uniform(10.0, 40.0)), vmin=0.0, eigensystem=kind == "bingham_diag", seed=int(rng.integers(1 << 30)))
+    return pdf, d, f"{kind} d={d}"
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_screen_takes_only_the_decisions_it_can_guarantee(gs, case):
+    """Random targets of every lane-kernel shape (d = 3 .. 16; mixtures of up to 10 components, eigenbasis and dense Bingham), both
+    samplers, the library stream and numpy's: the single-precision screen must not change a decision.  d <= 10: the screened
+    kernel against the all-double lane kernel, every state bit; d = 11 .. 16: against itself with every try left to the
+    double-precision decision (GSSS_VARIANT_FAST_VERIFY) bit for bit, and against the all-double cooperative kernel in every
+    integer output.  (geosss/mcmc.py:389, 397: the acceptance test is the reference's double-precision comparison.)"""
+    import torch
+    rng = np.random.default_rng(5000 + case)
+    numpy_stream = case % 4 == 3
+    pdf, d, what = _any_target(gs, rng, range(3, 11) if numpy_stream else range(3, 17))
+    n = int(rng.integers(2_000, 60_000))
+    n_steps = int(rng.integers(10, 60))
+    sampler = "reject" if rng.random() < 0.25 else "shrink"
+    if sampler == "reject":
+        n, n_steps = max(500, n // 8), max(4, n_steps // 3)
+    cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+    seed = int(rng.integers(1 << 30))
+    split = int(rng.integers(1, n_steps))
+    out = {}
+    for screen in (True, False) + (("verify",) if d > 10 else ()):
+        kw = dict(rng="numpy") if numpy_stream else {}
+        s = cls(pdf, x0, np.random.SeedSequence(seed) if numpy_stream else seed, mode="fast", placement="packed", screen=screen, **kw)
+        a = s.advance(split, thin=1)
+        b = s.advance(n_steps - split, thin=1)
+        assert int((s._err != 0).sum().item()) == 0
+        out[screen] = (torch.cat([a, b]), s.state_device.clone(), s._n_tries.clone(), s._n_reject.clone()) + ((s._rng_state.clone(),) if numpy_stream else ())
+    info = (what, n, n_steps, sampler, "numpy" if numpy_stream else "philox")
+    for i in (2, 3) + ((4,) if numpy_stream else ()):
+        assert torch.equal(out[True][i], out[False][i]), (i, info)
+    if d <= 10:
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]), info
+    else:
+        assert float((out[True][0] - out[False][0]).abs().max().item()) < 1e-11, info
+        for i in range(4):
+            assert torch.equal(out[True][i], out["verify"][i]), (i, info)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_splitting_a_run_over_launches_does_not_change_a_bit(gs, case):
+    """A chain's draws are keyed by (seed, chain, global step): n steps in one launch or in any split give the same bits -- lane
+    kernels (d <= 16) and the four- / eight-lane group kernels, which form every coefficient from x at every step; chain blocks
+    launched separately with their chain_offset (a shard of an ensemble, ensemble.py) included."""
+    import torch
+    rng = np.random.default_rng(3000 + case)
+    if case % 3 == 2:
+        d = int(rng.choice([4, 7, 10, 16, 24, 40, 50, 64, 100, 128]))
+        knots = gs.brownian_curve(int(rng.choice([3, 10, 10])), d, 0.5, seed=int(rng.integers(1 << 30)))
+        pdf, what = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), float(rng.choice([300.0, 800.0]))), f"curve d={d}"
+    else:
+        pdf, d, what = _any_target(gs, rng, range(3, 17))
+    n = int(rng.integers(3_000, 50_000))
+    n_steps = int(rng.integers(20, 300))
+    thin = int(rng.choice([1, 3, 10]))
+    n_steps -= n_steps % thin
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+    seed = int(rng.integers(1 << 30))
+    whole = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed, mode="fast", placement="packed")
+    rows = whole.advance(n_steps, thin=thin)
+    cuts = sorted(set(int(c) * thin for c in rng.integers(1, max(2, n_steps // thin), size=3)))
+    parts = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed, mode="fast", placement="packed")
+    got, done = [], 0
+    for c in cuts + [n_steps]:
+        if c > done:
+            got.append(parts.advance(c - done, thin=thin))
+            done = c
+    info = (what, n, n_steps, thin, cuts)
+    assert torch.equal(torch.cat(got), rows) and torch.equal(parts.state_device, whole.state_device) and torch.equal(parts._n_tries, whole._n_tries), info
+    # the second half of the chains as a shard of its own
+    lo = n // 2 + int(rng.integers(0, 100))
+    shard = gs.ShrinkageSphericalSliceSampler(pdf, x0[lo:], seed=seed, mode="fast", placement="packed", chain_offset=lo)
+    srows = shard.advance(n_steps, thin=thin)
+    assert torch.equal(srows, rows[:, :, lo:]) and torch.equal(shard._n_tries, whole._n_tries[lo:]), info
