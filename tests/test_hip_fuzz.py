@@ -263,3 +263,50 @@ def test_splitting_a_run_over_launches_does_not_change_a_bit(gs, case):
     shard = gs.ShrinkageSphericalSliceSampler(pdf, x0[lo:], seed=seed, mode="fast", placement="packed", chain_offset=lo)
     srows = shard.advance(n_steps, thin=thin)
     assert torch.equal(srows, rows[:, :, lo:]) and torch.equal(shard._n_tries, whole._n_tries[lo:]), info
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_running_statistics_do_not_depend_on_the_launch_choices(gs, case, monkeypatch):
+    """The running statistics (gsss_run_args.stats_dev: moments, lag sums, hops, mode counts; utils.py:96-134 on a series that is
+    never stored) are sums over a chain's kept states in time order: packing, slicing and the split over launches must leave every
+    accumulator bit as it is -- lane kernels and curve group kernels, with and without stored rows beside them."""
+    import torch
+    rng = np.random.default_rng(1000 + case)
+    curve = case % 3 == 2
+    if curve:
+        d = int(rng.choice([5, 10, 24, 50, 100, 200]))
+        knots = gs.brownian_curve(10, d, 0.5, seed=int(rng.integers(1 << 30)))
+        pdf, what = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 800.0), f"curve d={d}"
+        per = 64 if d <= 64 else (32 if d <= 128 else 16)
+        n = int(rng.integers(780, 1100)) * per - int(rng.integers(0, per))
+    else:
+        pdf, d, what = _any_target(gs, rng, range(3, 11))
+        n = int(rng.choice([768, 1024, 1280])) * int(rng.choice([256, 512])) + int(rng.integers(1, 50)) * 256 - int(rng.integers(0, 255))
+    thin = int(rng.choice([1, 4, 25]))
+    launches = [int(rng.integers(2, 5)) * 128 + int(rng.integers(0, 128)) for _ in range(2)]
+    keep = bool(rng.random() < 0.5)
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+    seed = int(rng.integers(1 << 30))
+    out = {}
+    for label, env in (("default", {}), ("plain", OFF)):
+        for k in OFF:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed, mode="fast", placement="packed").enable_stats(lags=8)
+        sliced = False
+        for m in launches:
+            m -= m % thin
+            if keep:
+                s.advance(m, thin=max(thin, -(-m // 8)))               # (stored rows beside the statistics, a few of them)
+            else:
+                s.advance(m, thin=thin, keep=False)
+            steps = C.c_int32(0)
+            s._lib.gsss_last_launch(None, C.byref(steps), None)
+            sliced = sliced or steps.value != 0
+        out[label] = (s._stats["acc"].clone(), s.state_device.clone(), sliced)
+    info = (what, n, thin, launches, keep, "sliced" if out["default"][2] else "unsliced")
+    assert not out["plain"][2], info
+    assert torch.equal(out["default"][1], out["plain"][1]), info
+    assert torch.equal(out["default"][0], out["plain"][0]), info
+    assert float(out["default"][0].abs().sum().item()) > 0.0
