@@ -310,3 +310,92 @@ def test_running_statistics_do_not_depend_on_the_launch_choices(gs, case, monkey
     assert torch.equal(out["default"][1], out["plain"][1]), info
     assert torch.equal(out["default"][0], out["plain"][0]), info
     assert float(out["default"][0].abs().sum().item()) > 0.0
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_baseline_samplers_split_and_shard_invariance(gs, case):
+    """RWMH / HMC / independence / mixture kernels (geosss/mcmc.py:118-332) on the counter-based stream: a run split over launches
+    at random, and the upper part of the ensemble run as a shard of its own (chain_offset), give the bits of the whole -- states,
+    accept counts, adapted stepsizes (the adaptation window `reset(burn)` counts a chain's own proposals)."""
+    import torch
+    rng = np.random.default_rng(2000 + case)
+    if case % 4 == 3:
+        d = int(rng.choice([5, 10, 24, 50]))
+        knots = gs.brownian_curve(10, d, 0.5, seed=int(rng.integers(1 << 30)))
+        pdf, what = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 300.0), f"curve d={d}"
+    else:
+        pdf, d, what = _any_target(gs, rng, [3, 4, 5, 8, 10, 12, 20])
+    kind = ["rwmh", "hmc", "indep", "mix"][case % 4 if case < 16 else int(rng.integers(0, 4))]
+    n = int(rng.integers(200, 5000))
+    n_steps, burn = int(rng.integers(10, 60)), int(rng.integers(0, 20))
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+    seed = int(rng.integers(1 << 30))
+
+    def build(x, **kw):
+        if kind == "rwmh":
+            return gs.MetropolisHastings(pdf, x, seed, stepsize=0.3, **kw)
+        if kind == "hmc":
+            return gs.SphericalHMC(pdf, x, seed, stepsize=0.02, n_steps=int(5), **kw)
+        if kind == "indep":
+            return gs.IndependenceSampler(pdf, x, seed, **kw)
+        return gs.MixtureRWMHIndependenceSampler(pdf, x, seed, stepsize=0.3, mixing_probability=0.3, **kw)
+
+    def grab(s):
+        return (s.state_device.clone(), s._n_accept.clone(), s._stepsize.clone())
+
+    whole = build(x0)
+    whole.reset(burn)
+    whole.advance(n_steps)
+    parts = build(x0)
+    parts.reset(burn)
+    done = 0
+    for c in sorted(set(int(v) for v in rng.integers(1, n_steps, size=3))) + [n_steps]:
+        parts.advance(c - done)
+        done = c
+    lo = n // 2 + int(rng.integers(0, 50))
+    shard = build(x0[lo:], chain_offset=lo)
+    shard.reset(burn)
+    shard.advance(n_steps)
+    info = (what, kind, n, n_steps, burn)
+    for a, b in zip(grab(whole), grab(parts)):
+        assert torch.equal(a, b), info
+    w, sh = grab(whole), grab(shard)
+    assert torch.equal(w[0][:, lo:], sh[0]) and torch.equal(w[1][lo:], sh[1]) and torch.equal(w[2][lo:], sh[2]), info
+    assert 0 < int(w[1].sum().item()) <= n * n_steps, info
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_sample_api_against_plain_launches(gs, case, monkeypatch):
+    """`Sampler.sample(n_samples, burnin, thin)` (geosss/mcmc.py:55-77: the state after every thin-th of burnin + n_samples thin...
+    steps, burn-in dropped) through the library's own row handling -- rows written in place in (chains, draws, dims) order, launches
+    capped at 4096 steps, rows held back, sliced rounds -- equals the rows picked by hand from unit launches of the plain
+    configuration, for random n_samples / burnin / thin and repeated calls."""
+    import torch
+    rng = np.random.default_rng(4000 + case)
+    pdf, d, what = _any_target(gs, rng, range(3, 11))
+    n = int(rng.choice([1, 7, 300, 5000, 20_000]))
+    n_samples, thin = int(rng.integers(1, 40)), int(rng.choice([1, 1, 2, 5, 13]))
+    burnin = int(rng.integers(0, 30)) if rng.random() < 0.7 else float(rng.choice([0.1, 0.25]))
+    x0 = gs.sample_sphere_device(d - 1, n, seed=int(rng.integers(1 << 30))).T
+    seed = int(rng.integers(1 << 30))
+    for k in OFF:
+        monkeypatch.delenv(k, raising=False)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed, placement="packed", mode="fast")
+    first = s.sample(n_samples, burnin=burnin, thin=thin, as_tensor=True)
+    second = s.sample(5, thin=thin, as_tensor=True)
+    for k, v in OFF.items():
+        monkeypatch.setenv(k, v)
+    r = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=seed, placement="packed", mode="fast")
+    n_burn = gs.mcmc.determine_burnin(n_samples, burnin)
+    info = (what, n, n_samples, burnin, thin)
+
+    def by_hand(n_rows, skip):
+        if skip:
+            r.advance(skip)
+        rows = [r.state_device.T.clone()[:, None, :]]                           # row 0: the state the call starts from (mcmc.py:64)
+        if n_rows > 1:
+            rows.append(r.advance((n_rows - 1) * thin, thin=thin).permute(2, 0, 1))
+        return torch.cat(rows, dim=1)
+
+    assert torch.equal(first.reshape(n, n_samples, d), by_hand(n_samples, n_burn)), info
+    assert torch.equal(second.reshape(n, 5, d), by_hand(5, 0)), info
