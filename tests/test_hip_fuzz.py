@@ -399,3 +399,80 @@ def test_sample_api_against_plain_launches(gs, case, monkeypatch):
 
     assert torch.equal(first.reshape(n, n_samples, d), by_hand(n_samples, n_burn)), info
     assert torch.equal(second.reshape(n, 5, d), by_hand(5, 0)), info
+
+
+@pytest.fixture(scope="module")
+def oracle_mod():
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def _edge_target(gs, oracle, rng, d):
+    """Targets at the edges of their families: the reference accepts them all (distributions.py:84-86, 156-157, 209-227, 272-275)"""
+    kind = rng.choice(["vmf_flat", "vmf_sharp", "vmf_twins", "vmf_zero_weight", "bingham_flat", "bingham_repeated", "bingham_sharp",
+                       "curve_two_knots", "curve_short_segments", "curve_sharp"])
+    seed = int(rng.integers(1 << 30))
+    if kind.startswith("vmf"):
+        k = int(rng.choice([1, 2, 3, 6, 10]))
+        dirs = gs.sample_sphere(d - 1, k, seed=seed)
+        # (kappa < 714: the reference's log(i0(kappa)) overflows beyond, distributions.py:157 -- the oracle follows it, the device does not)
+        kappa = {"vmf_flat": rng.uniform(0.0, 1e-3, k), "vmf_sharp": rng.uniform(300.0, 700.0, k)}.get(kind, rng.uniform(10.0, 100.0, k))
+        if kind == "vmf_twins" and k >= 2:
+            dirs[1] = dirs[0]                                                  # two components on the same mean
+        w = rng.uniform(0.5, 2.0, k)
+        if kind == "vmf_zero_weight" and k >= 2:
+            w[int(rng.integers(0, k))] = 0.0
+        mu = kappa[:, None] * dirs
+        return gs.MixtureModel([gs.VonMisesFisher(m) for m in mu], w), oracle.Target.vmf_mixture(mu, w), f"{kind} d={d} K={k}"
+    if kind.startswith("bingham"):
+        q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        lam = {"bingham_flat": np.zeros(d), "bingham_repeated": np.repeat(rng.uniform(0.0, 30.0, (d + 1) // 2), 2)[:d],
+               "bingham_sharp": np.sort(rng.uniform(0.0, 400.0, d))}[kind]
+        if rng.random() < 0.5:
+            q = np.eye(d)                                                      # the eigenbasis kernels
+        A = (q * lam) @ q.T
+        A = 0.5 * (A + A.T)
+        return gs.Bingham(A), oracle.Target.bingham(A), f"{kind} d={d} {'diag' if q[0, 0] == 1.0 and np.count_nonzero(q) == d else 'dense'}"
+    if kind == "curve_two_knots":
+        knots = gs.brownian_curve(2, d, 0.5, seed=seed)
+    elif kind == "curve_short_segments":
+        knots = gs.brownian_curve(10, d, 0.02, seed=seed)                      # sin(theta_g) ~ 0.02: the screen's margin grows with 1 / sin
+    else:
+        knots = gs.brownian_curve(int(rng.choice([5, 10])), d, 0.5, seed=seed)
+    kappa = 5000.0 if kind == "curve_sharp" else float(rng.choice([50.0, 300.0]))
+    return gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), kappa), oracle.Target.curve_vmf(knots, kappa), f"{kind} d={d} kappa={kappa}"
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_edge_targets_match_oracle(gs, oracle_mod, case):
+    """Targets at the edges of their families -- flat and very sharp mixtures, coincident components, a zero weight, Bingham with
+    all-equal / repeated / widely spread eigenvalues, curves of two knots, of very short segments, at kappa = 5000 -- in every
+    dimension range, both samplers: packed throughput kernels against the CPU oracle on the same Philox stream, states at 1e-10,
+    tries exact, no error flag; where a screened kernel runs, its decisions are the all-double ones."""
+    import torch
+    oracle = oracle_mod
+    rng = np.random.default_rng(6000 + case)
+    d = int(rng.choice([3, 3, 4, 6, 8, 10, 12, 16, 24, 50, 130]))
+    pdf, tgt, what = _edge_target(gs, oracle, rng, d)
+    n, n_steps = (1500, 60) if d <= 16 else (300, 30)
+    sampler = "reject" if rng.random() < 0.2 and "sharp" not in what else "shrink"
+    if sampler == "reject":
+        n_steps = 8
+    cls = gs.RejectionSphericalSliceSampler if sampler == "reject" else gs.ShrinkageSphericalSliceSampler
+    kind = oracle.REJECT if sampler == "reject" else oracle.SHRINK
+    x0 = oracle.sample_sphere(int(rng.integers(1 << 20)), n, d)
+    seed = int(rng.integers(1 << 30))
+    want = oracle.run(tgt, x0, n_steps, seed=seed, sampler=kind, n_threads=16)
+    s = cls(pdf, x0, seed=seed, placement="packed")
+    name = s._lib.gsss_kernel_name(s._target_dev.handle, 1, 0, 1).decode() if s.mode == "fast" else "exact"
+    kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
+    info = (what, sampler, s.mode, name)
+    assert np.all(want["err"] == 0) and np.all(s.errors == 0), info
+    assert np.array_equal(s.n_tries_per_chain, want["n_tries"]), info
+    assert np.max(np.abs(kept - want["samples"])) < 1e-10, info
