@@ -476,3 +476,48 @@ def test_edge_targets_match_oracle(gs, oracle_mod, case):
     assert np.all(want["err"] == 0) and np.all(s.errors == 0), info
     assert np.array_equal(s.n_tries_per_chain, want["n_tries"]), info
     assert np.max(np.abs(kept - want["samples"])) < 1e-10, info
+
+
+def test_concurrent_host_threads_and_streams(gs):
+    """Four host threads, each with its own HIP stream and samplers of its own (lane kernel with a sliced last round, group kernel
+    with every chunk sliced, exact kernel, RWMH), launching at the same time: the library's host side keeps per-thread error text
+    and launch records and one mutex-guarded cache of occupancy queries -- every thread gets the bits of its serial run."""
+    import threading
+    import torch
+
+    def work(i, out):
+        rng = np.random.default_rng(800 + i)
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            res = []
+            for rep in range(3):
+                pdf, d, _ = _any_target(gs, rng, [3, 5, 10])
+                n = 1280 * 256 + 37 * 256 - 11 * i
+                x0 = gs.sample_sphere_device(d - 1, n, seed=10 * i + rep).T
+                s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=i, mode="fast", placement="packed")
+                rows = s.advance(300, thin=100)
+                knots = gs.brownian_curve(10, 10 + 7 * i, 0.5, seed=i)
+                c = gs.ShrinkageSphericalSliceSampler(gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 300.0),
+                                                     gs.sample_sphere_device(9 + 7 * i, 60_000, seed=i).T, seed=i, mode="fast", placement="packed")
+                c.advance(260)
+                e = gs.ShrinkageSphericalSliceSampler(pdf, x0[:2000], seed=i, mode="exact")
+                e.advance(20)
+                m = gs.MetropolisHastings(pdf, x0[:3000], i, stepsize=0.3)
+                m.advance(30)
+                torch.cuda.current_stream().synchronize()
+                res.append([t.clone() for t in (rows, s.state_device, s._n_tries, c.state_device, c._n_tries, e.state_device, m.state_device, m._n_accept)])
+            out[i] = res
+
+    serial, threaded = {}, {}
+    for i in range(4):
+        work(i, serial)
+    threads = [threading.Thread(target=work, args=(i, threaded)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(threaded) == [0, 1, 2, 3]
+    for i in range(4):
+        for a, b in zip(serial[i], threaded[i]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), i
