@@ -1032,16 +1032,37 @@ struct VmfMixture {
 
 template <class V>
 struct Bingham {
-    const double *A;  // LDS [d][DPAD]: rows of A, columns zero padded
-    const double *b;  // LDS [DPAD]: BinghamFisher linear term (zeros for a plain Bingham)
+    const double *A;   // LDS [d][DPAD]: rows of A, columns zero padded
+    const double *Ag;  // ... or, where d^2 doubles do not fit in LDS (d > 128), the blob's own rows [d][d] in global memory (L2)
+    const double *b;   // LDS [DPAD]: BinghamFisher linear term (zeros for a plain Bingham)
     int d;
-    __host__ __device__ static size_t lds_doubles(int /*k*/, int d) { return (size_t)(d + 1) * V::DPAD; }
+    // (host and device take the same decision from (d, DPAD): 136 KB leave room for the groups' scratch rows and the tables)
+    __host__ __device__ static bool in_lds(int d) { return (size_t)(d + 1) * V::DPAD * sizeof(double) <= (size_t)136 * 1024; }
+    __host__ __device__ static size_t lds_doubles(int /*k*/, int d) { return in_lds(d) ? (size_t)(d + 1) * V::DPAD : (size_t)V::DPAD; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         d = tb.d;
-        lds_fill(lds, tb.d + 1, V::DPAD, tb.blob, tb.d);  // blob = A rows followed by b
-        A = lds;
-        b = lds + (size_t)tb.d * V::DPAD;
+        if (in_lds(tb.d)) {
+            lds_fill(lds, tb.d + 1, V::DPAD, tb.blob, tb.d);  // blob = A rows followed by b
+            A = lds;
+            Ag = nullptr;
+            b = lds + (size_t)tb.d * V::DPAD;
+        } else {
+            lds_fill(lds, 1, V::DPAD, tb.blob + (size_t)tb.d * tb.d, tb.d);
+            A = nullptr;
+            Ag = tb.blob;
+            b = lds;
+        }
+    }
+    // row i of A at this lane's slots, from global memory
+    __device__ __forceinline__ void row_global(int i, int g, double (&r)[V::N]) const
+    {
+        const double *row = Ag + (size_t)i * d;
+#pragma unroll
+        for (int j = 0; j < V::N; ++j) {
+            const int c = V::comp(g, j);
+            r[j] = c < d ? row[c] : 0.0;
+        }
     }
     __device__ __forceinline__ double linear(const double (&y)[V::N], int g) const
     {
@@ -1073,10 +1094,20 @@ struct Bingham {
             double xa[V::N];
 #pragma unroll
             for (int j = 0; j < V::N; ++j) xa[j] = 0.0;
-            for (int i = 0; i < d; ++i) {
-                const double yi = scratch[i];
+            if (Ag == nullptr) {
+                for (int i = 0; i < d; ++i) {
+                    const double yi = scratch[i];
 #pragma unroll
-                for (int j = 0; j < V::N; ++j) xa[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], xa[j]);
+                    for (int j = 0; j < V::N; ++j) xa[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], xa[j]);
+                }
+            } else {  // (the same products in the same order: the same bits as the LDS copy would give)
+                for (int i = 0; i < d; ++i) {
+                    const double yi = scratch[i];
+                    double r[V::N];
+                    row_global(i, g, r);
+#pragma unroll
+                    for (int j = 0; j < V::N; ++j) xa[j] = fma(yi, r[j], xa[j]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < V::N; ++j) s = fma(xa[j], y[j], s);
@@ -1105,10 +1136,20 @@ struct Bingham {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int j = 0; j < V::N; ++j) out[j] = 0.0;
-            for (int i = 0; i < d; ++i) {  // (A y)_j = sum_i A_ij y_i for the lane's own components j (A symmetric)
-                const double yi = scratch[i];
+            if (Ag == nullptr) {
+                for (int i = 0; i < d; ++i) {  // (A y)_j = sum_i A_ij y_i for the lane's own components j (A symmetric)
+                    const double yi = scratch[i];
 #pragma unroll
-                for (int j = 0; j < V::N; ++j) out[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], out[j]);
+                    for (int j = 0; j < V::N; ++j) out[j] = fma(yi, A[i * V::DPAD + V::comp(g, j)], out[j]);
+                }
+            } else {
+                for (int i = 0; i < d; ++i) {
+                    const double yi = scratch[i];
+                    double r[V::N];
+                    row_global(i, g, r);
+#pragma unroll
+                    for (int j = 0; j < V::N; ++j) out[j] = fma(yi, r[j], out[j]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < V::N; ++j) out[j] *= 2.0;

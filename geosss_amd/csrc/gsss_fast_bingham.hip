@@ -36,8 +36,12 @@ int launch_fast_bingham(const TargetBlock &tb, const RunBlock &rb, bool replay, 
         default: break;
         }
     }
-    // larger d: lanes cooperate on one chain (A must fit the LDS: d <= 128)
-    if (tb.d > 10 && tb.d <= 128) {
+    // larger d: lanes cooperate on one chain.  A must fit the LDS beside the groups' scratch rows: d <= 126 ((d + 1) x 128 doubles
+    // of rows + 16 groups x 258 of scratch in 160 KB) -- beyond, fast mode is not offered and mode "auto" runs the exact kernels
+    // (which read a dense A of d > 128 from global memory)
+    using Wide = CoopBingham<CoopVec<16, 8>>;
+    const bool fits = tb.d <= 64 || (coop_param_doubles<Wide>(tb.d) + (size_t)Wide::kScratchPerGroup * (kBlock / 16)) * sizeof(double) <= 160 * 1024;
+    if (tb.d > 10 && tb.d <= 128 && fits) {
         // Lanes per chain x slots per lane, measured at 10^5 chains (10^9 chain-steps/s, eigenbasis / dense A): d <= 32 four
         // lanes with eight slots 5.3 / 3.5 against 2.4 / 1.8 for sixteen lanes with four (the per-step serial work -- Philox
         // and Box-Muller rounds, reductions, the try loop -- is repeated in every lane of a group, and sixteen groups share a

@@ -11,9 +11,13 @@ one the oracle tests of test_hip_parity.py hold to the reference's chains.  (geo
 thin-th state of every chain, whatever the launch shape.)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
+
+# GSSS_FUZZ_SCALE=k runs k times the cases (a soak run on the GPU box; the default suite stays at a few seconds)
+SCALE = max(1, int(os.environ.get("GSSS_FUZZ_SCALE", "1")))
 
 pytestmark = pytest.mark.gpu
 
@@ -71,7 +75,7 @@ def _run(gs, torch, pdf, d, x0, cfg, env, monkeypatch):
     return dict(rows=outs, state=s.state_device.clone(), tries=s._n_tries.clone(), rej=s._n_reject.clone(), err=s._err.clone(), sliced=sliced, kernel=name)
 
 
-@pytest.mark.parametrize("case", range(96))
+@pytest.mark.parametrize("case", range(96 * SCALE))
 def test_launch_choices_do_not_change_a_bit(gs, case, monkeypatch):
     import torch
     rng = np.random.default_rng(9000 + case)
@@ -108,7 +112,7 @@ def test_launch_choices_do_not_change_a_bit(gs, case, monkeypatch):
 
 def test_the_cases_covered_the_choices():
     """(runs behind the cases above) the draw of cases did reach what this file is about"""
-    if SEEN["cases"] < 96:
+    if SEEN["cases"] < 96 * SCALE:
         pytest.skip("not every case ran in this process")
     assert SEEN["sliced"] >= 10 and SEEN["chain_major"] >= 30 and SEEN["bingham_chain_major_open_end"] >= 10 and SEEN["stopped_chains"] >= 10, SEEN
 
@@ -116,7 +120,7 @@ def test_the_cases_covered_the_choices():
 CURVE_SEEN = {"cases": 0, "sliced": 0}
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", range(40 * SCALE))
 def test_group_kernel_slicing_does_not_change_a_bit(gs, case, monkeypatch):
     """The group-speculative curve kernels cut EVERY chunk of a launch into step slices once the chunks outnumber the resident
     workgroups: any dimension 4 .. 256 (lane groups of 4, 8, 16; one to four component quads a lane), 2 .. 17 knots, ragged
@@ -173,7 +177,7 @@ def test_group_kernel_slicing_does_not_change_a_bit(gs, case, monkeypatch):
 
 
 def test_the_curve_cases_were_sliced():
-    if CURVE_SEEN["cases"] < 40:
+    if CURVE_SEEN["cases"] < 40 * SCALE:
         pytest.skip("not every case ran in this process")
     assert CURVE_SEEN["sliced"] >= 12, CURVE_SEEN
 
@@ -189,7 +193,7 @@ def _any_target(gs, rng, dims):
     return pdf, d, f"{kind} d={d}"
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", range(40 * SCALE))
 def test_screen_takes_only_the_decisions_it_can_guarantee(gs, case):
     """Random targets of every lane-kernel shape (d = 3 .. 16; mixtures of up to 10 components, eigenbasis and dense Bingham), both
     samplers, the library stream and numpy's: the single-precision screen must not change a decision.  d <= 10: the screened
@@ -228,7 +232,7 @@ def test_screen_takes_only_the_decisions_it_can_guarantee(gs, case):
             assert torch.equal(out[True][i], out["verify"][i]), (i, info)
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(24 * SCALE))
 def test_splitting_a_run_over_launches_does_not_change_a_bit(gs, case):
     """A chain's draws are keyed by (seed, chain, global step): n steps in one launch or in any split give the same bits -- lane
     kernels (d <= 16) and the four- / eight-lane group kernels, which form every coefficient from x at every step; chain blocks
@@ -265,7 +269,7 @@ def test_splitting_a_run_over_launches_does_not_change_a_bit(gs, case):
     assert torch.equal(srows, rows[:, :, lo:]) and torch.equal(shard._n_tries, whole._n_tries[lo:]), info
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(24 * SCALE))
 def test_running_statistics_do_not_depend_on_the_launch_choices(gs, case, monkeypatch):
     """The running statistics (gsss_run_args.stats_dev: moments, lag sums, hops, mode counts; utils.py:96-134 on a series that is
     never stored) are sums over a chain's kept states in time order: packing, slicing and the split over launches must leave every
@@ -312,7 +316,7 @@ def test_running_statistics_do_not_depend_on_the_launch_choices(gs, case, monkey
     assert float(out["default"][0].abs().sum().item()) > 0.0
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(24 * SCALE))
 def test_baseline_samplers_split_and_shard_invariance(gs, case):
     """RWMH / HMC / independence / mixture kernels (geosss/mcmc.py:118-332) on the counter-based stream: a run split over launches
     at random, and the upper part of the ensemble run as a shard of its own (chain_offset), give the bits of the whole -- states,
@@ -364,7 +368,7 @@ def test_baseline_samplers_split_and_shard_invariance(gs, case):
     assert 0 < int(w[1].sum().item()) <= n * n_steps, info
 
 
-@pytest.mark.parametrize("case", range(20))
+@pytest.mark.parametrize("case", range(20 * SCALE))
 def test_sample_api_against_plain_launches(gs, case, monkeypatch):
     """`Sampler.sample(n_samples, burnin, thin)` (geosss/mcmc.py:55-77: the state after every thin-th of burnin + n_samples thin...
     steps, burn-in dropped) through the library's own row handling -- rows written in place in (chains, draws, dims) order, launches
@@ -449,7 +453,7 @@ def _edge_target(gs, oracle, rng, d):
     return gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), kappa), oracle.Target.curve_vmf(knots, kappa), f"{kind} d={d} kappa={kappa}"
 
 
-@pytest.mark.parametrize("case", range(48))
+@pytest.mark.parametrize("case", range(48 * SCALE))
 def test_edge_targets_match_oracle(gs, oracle_mod, case):
     """Targets at the edges of their families -- flat and very sharp mixtures, coincident components, a zero weight, Bingham with
     all-equal / repeated / widely spread eigenvalues, curves of two knots, of very short segments, at kappa = 5000 -- in every

@@ -307,7 +307,9 @@ def test_layout_round_trip(gs):
 
 SYNTH = [("vmf", 11, 6), ("vmf", 13, 4), ("vmf", 14, 2), ("vmf", 12, 7), ("vmf", 16, 10), ("vmf", 15, 11), ("bingham", 11, 0), ("bingham", 14, 0), ("bingham", 16, 0), ("bingham_diag", 12, 0),
          ("bingham_diag", 15, 0), ("bingham_diag", 16, 0),
-         ("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
+         ("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("bingham", 126, 0), ("bingham", 127, 0), ("bingham", 128, 0),
+         # dense A beyond what LDS holds (d > 128): the exact kernels read its rows from global memory (Bingham<V>::Ag)
+         ("bingham", 129, 0), ("bingham", 200, 0), ("bingham", 300, 0), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
          ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7),
          ("curve", 9, 10), ("curve", 15, 10), ("curve", 18, 10), ("curve", 21, 10), ("bingham", 7, 0), ("bingham", 9, 0),
          ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10),
@@ -365,6 +367,42 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k, monkeypatch):
     lp = pdf.log_prob(kept[:, -1])
     ref = tgt.log_prob(kept[:, -1])
     assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
+
+
+@pytest.mark.parametrize("d", [129, 150, 256, 400])
+def test_large_dense_bingham_reads_A_from_global_memory(gs, oracle, d):
+    """A dense A of d > 128 (more than 136 KB of rows) does not fit a workgroup's LDS: the exact kernels, log_prob / gradient and
+    the baseline samplers read its rows from global memory instead (Bingham<V>::Ag) -- same products in the same order.  A
+    Fisher-Bingham target (distributions.py:106-114) with a dense A, against the oracle: slice sampler chains on the Philox stream
+    at 1e-10 with exact tries, log_prob and gradient (2 A x, distributions.py:88-89), RWMH and HMC chains."""
+    rng = np.random.default_rng(d)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A = (q * rng.uniform(0.0, 25.0, d)) @ q.T
+    A = 0.5 * (A + A.T)
+    b = rng.standard_normal(d) * 3.0
+    pdf, tgt = gs.BinghamFisher(A, b), oracle.Target.bingham(A, b)
+    n, n_steps = 48, 10
+    x0 = oracle.sample_sphere(5, n, d)
+    want = oracle.run(tgt, x0, n_steps, seed=9, n_threads=8)
+    with pytest.warns(RuntimeWarning, match="no fast-mode kernel"):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=9)
+    assert s.mode == "exact"
+    kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
+    assert np.all(s.errors == 0) and np.array_equal(s.n_tries_per_chain, want["n_tries"])
+    assert np.max(np.abs(kept - want["samples"])) < TOL
+    X = kept[:, -1]
+    lp, ref = pdf.log_prob(X), tgt.log_prob(X)
+    assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
+    assert np.max(np.abs(pdf.gradient(X[:5]) - np.array([oracle.gradient(tgt, x) for x in X[:5]]))) < 1e-10 * np.abs(A).sum(axis=1).max()
+    for cls, kind, kw, okw in ((gs.MetropolisHastings, oracle.RWMH, dict(stepsize=0.05), {}),
+                               (gs.SphericalHMC, oracle.HMC, dict(stepsize=0.01, n_steps=4), dict(n_leapfrog=4))):
+        okw = dict(okw, stepsize=kw["stepsize"])
+        ref = oracle.mh_run(tgt, x0, 8, sampler=kind, adapt_steps=3, seed=2, n_threads=8, **okw)
+        m = cls(pdf, x0, 2, **kw)
+        m.reset(3)
+        m.advance(8)
+        assert np.array_equal(m.n_accept_per_chain, ref["n_accept"])
+        assert np.max(np.abs(m.state[:, :d] - ref["state"])) < (1e-8 if kind == oracle.HMC else 1e-10)
 
 
 # ------------------------------------------------------------------ numpy's own stream on the device
