@@ -405,6 +405,35 @@ def test_large_dense_bingham_reads_A_from_global_memory(gs, oracle, d):
         assert np.max(np.abs(m.state[:, :d] - ref["state"])) < (1e-8 if kind == oracle.HMC else 1e-10)
 
 
+def test_shape_limits(gs):
+    """What the kernels are not built for is refused with a ValueError that names the limit, never a wrong
+    answer or a fault: d > 512; target rows beyond a workgroup's LDS.  Just inside the limits everything runs (mode auto falls
+    back to the exact kernels where no fast kernel is built)."""
+    import warnings
+
+    def run(pdf, d):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = gs.ShrinkageSphericalSliceSampler(pdf, gs.sample_sphere(d - 1, 40, seed=1), seed=1)
+            s.advance(4)
+        assert np.all(s.errors == 0) and np.all(np.isfinite(s.state)) and np.all(np.isfinite(pdf.log_prob(s.state)))
+        return s.mode
+
+    def vmf(d, k):
+        return gs.MixtureModel([gs.VonMisesFisher(m) for m in 30.0 * gs.sample_sphere(d - 1, k, seed=2)])
+
+    def curve(d, k):
+        return gs.CurvedVonMisesFisher(gs.SlerpCurve(gs.brownian_curve(k, d, 0.5, seed=4)), 300.0)
+
+    assert run(vmf(3, 500), 3) == "exact" and run(vmf(50, 100), 50) == "exact" and run(vmf(512, 3), 512) == "exact"
+    assert run(gs.random_bingham(d=512, vmax=20.0, vmin=0.0, eigensystem=False, seed=3), 512) == "exact"
+    assert run(curve(10, 100), 10) == "exact" and run(curve(300, 18), 300) == "exact" and run(curve(512, 10), 512) == "fast"
+    for pdf, d, what in ((vmf(513, 3), 513, "max 512"), (curve(1000, 10), 1000, "max 512"), (curve(300, 60), 300, "of LDS"),
+                         (gs.random_bingham(d=600, vmax=20.0, vmin=0.0, eigensystem=True, seed=3), 600, "max 512")):
+        with pytest.raises(ValueError, match=what):
+            run(pdf, d)
+
+
 # ------------------------------------------------------------------ numpy's own stream on the device
 
 
