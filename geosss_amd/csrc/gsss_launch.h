@@ -18,6 +18,7 @@ using VC16x4 = CoopVec<16, 4>;
 using VC16x8 = CoopVec<16, 8>;
 using VC64x4 = CoopVec<64, 4>;
 using VC64x8 = CoopVec<64, 8>;
+using VC64x16 = CoopVec<64, 16>;
 
 #define GSSS_VEC_LIST(X) \
     X(1, VL2, "lane2")       \
@@ -32,7 +33,8 @@ using VC64x8 = CoopVec<64, 8>;
     X(10, VC16x4, "coop16x4") \
     X(11, VC16x8, "coop16x8") \
     X(12, VC64x4, "coop64x4") \
-    X(13, VC64x8, "coop64x8")
+    X(13, VC64x8, "coop64x8") \
+    X(14, VC64x16, "coop64x16")
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 
