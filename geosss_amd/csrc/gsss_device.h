@@ -975,29 +975,66 @@ __device__ __forceinline__ void lds_fill(double *dst, int n_rows, int dpad, cons
     }
 }
 
+// Target rows (component means, knots) live in LDS, zero padded to the layout's DPAD -- or, where they do not fit a workgroup's
+// LDS (many components or knots at large d), are read from the parameter blob in global memory as they are (stride d): the same
+// products in the same order.  Host and device take the decision from (rows, DPAD) alone; 136 KB leave room for scratch and tables.
+template <class V>
+__host__ __device__ constexpr bool rows_fit_lds(size_t doubles)
+{
+    return doubles * sizeof(double) <= (size_t)136 * 1024;
+}
+// component c of a row: LDS rows are padded with zeros, global rows end at d
+template <bool GLOBAL, class V>
+__device__ __forceinline__ double row_at(const double *row, int c, int d)
+{
+    if constexpr (GLOBAL)
+        return c < d ? row[c] : 0.0;
+    else
+        return row[c];
+}
+
 template <class V>
 struct VmfMixture {
-    const double *mu;    // LDS [K][DPAD]
-    const double *logc;  // LDS [K]
-    int K;
+    const double *mu;    // LDS [K][DPAD]; nullptr: the rows are read from `mug`
+    const double *mug;   // global [K][d]
+    const double *logc;  // [K], LDS or global like the rows
+    int K, d;
 
-    __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return (size_t)k * V::DPAD + k; }
+    __host__ __device__ static bool in_lds(int k) { return rows_fit_lds<V>((size_t)k * V::DPAD + k); }
+    __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return in_lds(k) ? (size_t)k * V::DPAD + k : 0; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         K = tb.k;
-        lds_fill(lds, K, V::DPAD, tb.blob, tb.d);
-        double *lc = lds + (size_t)K * V::DPAD;
-        for (int i = threadIdx.x; i < K; i += kBlock) lc[i] = tb.blob[(size_t)K * tb.d + i];
-        mu = lds;
-        logc = lc;
+        d = tb.d;
+        mug = tb.blob;
+        if (in_lds(K)) {
+            lds_fill(lds, K, V::DPAD, tb.blob, tb.d);
+            double *lc = lds + (size_t)K * V::DPAD;
+            for (int i = threadIdx.x; i < K; i += kBlock) lc[i] = tb.blob[(size_t)K * tb.d + i];
+            mu = lds;
+            logc = lc;
+        } else {
+            mu = nullptr;
+            logc = tb.blob + (size_t)K * tb.d;
+        }
+    }
+    template <bool G>
+    __device__ __forceinline__ const double *row(int k) const
+    {
+        return G ? mug + (size_t)k * d : mu + (size_t)k * V::DPAD;
+    }
+    template <bool G>
+    __device__ __forceinline__ double comp_logp_t(const double (&y)[V::N], int g, int k) const
+    {
+        const double *m = row<G>(k);
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) s = fma(y[i], row_at<G, V>(m, V::comp(g, i), d), s);
+        return V::reduce(s) + logc[k];
     }
     __device__ __forceinline__ double comp_logp(const double (&y)[V::N], int g, int k) const
     {
-        const double *m = mu + (size_t)k * V::DPAD;
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < V::N; ++i) s = fma(y[i], m[V::comp(g, i)], s);
-        return V::reduce(s) + logc[k];
+        return mu != nullptr ? comp_logp_t<false>(y, g, k) : comp_logp_t<true>(y, g, k);
     }
     // logsumexp_k( y.mu_k + logc_k )
     __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
@@ -1010,22 +1047,30 @@ struct VmfMixture {
         return amax + fm::log_fast(s);
     }
     // distributions.py:223-227 : sum_k exp(p_k) mu_k / exp(logsumexp(p))  (the softmax-weighted mean of the mu_k)
-    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
+    template <bool G>
+    __device__ __forceinline__ void grad_t(const double (&y)[V::N], int g, double (&out)[V::N]) const
     {
         double amax = -INFINITY;
-        for (int k = 0; k < K; ++k) amax = fmax(amax, comp_logp(y, g, k));
+        for (int k = 0; k < K; ++k) amax = fmax(amax, comp_logp_t<G>(y, g, k));
         double den = 0.0;
 #pragma unroll
         for (int i = 0; i < V::N; ++i) out[i] = 0.0;
         for (int k = 0; k < K; ++k) {
-            const double w = fm::exp_fast(comp_logp(y, g, k) - amax);
+            const double w = fm::exp_fast(comp_logp_t<G>(y, g, k) - amax);
             den += w;
-            const double *m = mu + (size_t)k * V::DPAD;
+            const double *m = row<G>(k);
 #pragma unroll
-            for (int i = 0; i < V::N; ++i) out[i] = fma(w, m[V::comp(g, i)], out[i]);
+            for (int i = 0; i < V::N; ++i) out[i] = fma(w, row_at<G, V>(m, V::comp(g, i), d), out[i]);
         }
 #pragma unroll
         for (int i = 0; i < V::N; ++i) out[i] /= den;
+    }
+    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
+    {
+        if (mu != nullptr)
+            grad_t<false>(y, g, out);
+        else
+            grad_t<true>(y, g, out);
     }
     static constexpr int kScratchPerChain = 0;
 };
@@ -1162,88 +1207,94 @@ struct Bingham {
 
 template <class V>
 struct CurveVmf {
-    const double *knots;  // LDS [K][DPAD]
-    const double *seg;    // LDS [K-1][4] : theta, cos(theta), sin(theta), sin(theta)+1e-10  (spherical_curve.py:28-31)
-    int K;
+    const double *knots;   // LDS [K][DPAD]; nullptr: the rows are read from `knotsg` (rows_fit_lds)
+    const double *knotsg;  // global [K][d]
+    const double *seg;     // [K-1][4] : theta, cos(theta), sin(theta), sin(theta)+1e-10  (spherical_curve.py:28-31); LDS or global like the rows
+    int K, d;
     double kappa;
-    __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return (size_t)k * V::DPAD + 4 * (size_t)(k - 1); }
+    __host__ __device__ static bool in_lds(int k) { return rows_fit_lds<V>((size_t)k * V::DPAD + 4 * (size_t)(k - 1)); }
+    __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return in_lds(k) ? (size_t)k * V::DPAD + 4 * (size_t)(k - 1) : 0; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
         K = tb.k;
+        d = tb.d;
         kappa = tb.kappa;
-        lds_fill(lds, K, V::DPAD, tb.blob, tb.d);
-        double *sg = lds + (size_t)K * V::DPAD;
-        for (int i = threadIdx.x; i < 4 * (K - 1); i += kBlock) sg[i] = tb.blob[(size_t)K * tb.d + i];
-        knots = lds;
-        seg = sg;
+        knotsg = tb.blob;
+        if (in_lds(K)) {
+            lds_fill(lds, K, V::DPAD, tb.blob, tb.d);
+            double *sg = lds + (size_t)K * V::DPAD;
+            for (int i = threadIdx.x; i < 4 * (K - 1); i += kBlock) sg[i] = tb.blob[(size_t)K * tb.d + i];
+            knots = lds;
+            seg = sg;
+        } else {
+            knots = nullptr;
+            seg = tb.blob + (size_t)K * tb.d;
+        }
     }
+    template <bool G>
+    __device__ __forceinline__ const double *row(int k) const
+    {
+        return G ? knotsg + (size_t)k * d : knots + (size_t)k * V::DPAD;
+    }
+    template <bool G>
     __device__ __forceinline__ double kdot(const double (&y)[V::N], int g, int k) const
     {
-        const double *a = knots + (size_t)k * V::DPAD;
+        const double *a = row<G>(k);
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < V::N; ++i) s = fma(a[V::comp(g, i)], y[i], s);
+        for (int i = 0; i < V::N; ++i) s = fma(row_at<G, V>(a, V::comp(g, i), d), y[i], s);
         return V::reduce(s);
     }
-    // kappa * (y . nearest(y)); nearest = closest point of the first segment of minimal distance
-    __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
+    // the segments in order: y . nearest of each, the first of minimal distance wins; `keep(near)` is called for every new best
+    template <bool G, class Keep>
+    __device__ __forceinline__ double scan(const double (&y)[V::N], int g, Keep keep) const
     {
         double best = INFINITY, best_dot = 0.0;
-        double ay = kdot(y, g, 0);
+        double ay = kdot<G>(y, g, 0);
         for (int s = 0; s + 1 < K; ++s) {
-            const double by = kdot(y, g, s + 1);
+            const double by = kdot<G>(y, g, s + 1);
             const double theta = seg[4 * s], ct = seg[4 * s + 1], st = seg[4 * s + 2], den = seg[4 * s + 3];
             double t = atan2(by - ay * ct, ay * st);
             t = fmin(fmax(t, 0.0), theta);
             const double sa = sin(theta - t), sb = sin(t);
-            const double *a = knots + (size_t)s * V::DPAD, *b = a + V::DPAD;
-            double xy = 0.0;
-#pragma unroll
-            for (int i = 0; i < V::N; ++i) {
-                const int c = V::comp(g, i);
-                const double near_i = (sa * a[c] + sb * b[c]) / den;
-                xy = fma(y[i], near_i, xy);
-            }
-            xy = V::reduce(xy);
-            const double dist = acos(fmin(fmax(xy, -1.0), 1.0));
-            if (dist < best) {
-                best = dist;
-                best_dot = xy;
-            }
-            ay = by;
-        }
-        return kappa * best_dot;
-    }
-    // distributions.py:277-278 : kappa * find_nearest(y)
-    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
-    {
-        double best = INFINITY;
-#pragma unroll
-        for (int i = 0; i < V::N; ++i) out[i] = 0.0;
-        double ay = kdot(y, g, 0);
-        for (int s = 0; s + 1 < K; ++s) {
-            const double by = kdot(y, g, s + 1);
-            const double theta = seg[4 * s], ct = seg[4 * s + 1], st = seg[4 * s + 2], den = seg[4 * s + 3];
-            double t = atan2(by - ay * ct, ay * st);
-            t = fmin(fmax(t, 0.0), theta);
-            const double sa = sin(theta - t), sb = sin(t);
-            const double *a = knots + (size_t)s * V::DPAD, *b = a + V::DPAD;
+            const double *a = row<G>(s), *b = row<G>(s + 1);
             double near[V::N], xy = 0.0;
 #pragma unroll
             for (int i = 0; i < V::N; ++i) {
                 const int c = V::comp(g, i);
-                near[i] = (sa * a[c] + sb * b[c]) / den;
+                near[i] = (sa * row_at<G, V>(a, c, d) + sb * row_at<G, V>(b, c, d)) / den;
                 xy = fma(y[i], near[i], xy);
             }
             xy = V::reduce(xy);
             const double dist = acos(fmin(fmax(xy, -1.0), 1.0));
             if (dist < best) {
                 best = dist;
-#pragma unroll
-                for (int i = 0; i < V::N; ++i) out[i] = kappa * near[i];
+                best_dot = xy;
+                keep(near);
             }
             ay = by;
         }
+        return best_dot;
+    }
+    // kappa * (y . nearest(y)); nearest = closest point of the first segment of minimal distance
+    __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
+    {
+        auto nothing = [](const double (&)[V::N]) {};
+        return kappa * (knots != nullptr ? scan<false>(y, g, nothing) : scan<true>(y, g, nothing));
+    }
+    // distributions.py:277-278 : kappa * find_nearest(y)
+    __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
+    {
+#pragma unroll
+        for (int i = 0; i < V::N; ++i) out[i] = 0.0;
+        auto keep = [&](const double (&near)[V::N]) {
+#pragma unroll
+            for (int i = 0; i < V::N; ++i) out[i] = kappa * near[i];
+        };
+        if (knots != nullptr)
+            (void)scan<false>(y, g, keep);
+        else
+            (void)scan<true>(y, g, keep);
     }
     static constexpr int kScratchPerChain = 0;
 };

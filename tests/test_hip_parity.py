@@ -311,7 +311,9 @@ SYNTH = [("vmf", 11, 6), ("vmf", 13, 4), ("vmf", 14, 2), ("vmf", 12, 7), ("vmf",
          # dense A beyond what LDS holds (d > 128): the exact kernels read its rows from global memory (Bingham<V>::Ag)
          ("bingham", 129, 0), ("bingham", 200, 0), ("bingham", 300, 0),
          # d = 513 .. 1024: sixty-four lanes with sixteen slots each (round 4)
-         ("bingham", 600, 0), ("bingham_diag", 1024, 0), ("vmf", 513, 3), ("vmf", 1000, 12), ("curve", 700, 10), ("curve", 1024, 17), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
+         ("bingham", 600, 0), ("bingham_diag", 1024, 0), ("vmf", 513, 3), ("vmf", 1000, 12), ("curve", 700, 10), ("curve", 1024, 17),
+         # target rows read from global memory: more components / knots than a workgroup's LDS holds at that d
+         ("vmf", 600, 40), ("vmf", 3, 7000), ("curve", 300, 60), ("curve", 1000, 25), ("vmf", 100, 200), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
          ("curve", 6, 10), ("curve", 12, 10), ("curve", 100, 10), ("curve", 300, 10), ("curve", 9, 7),
          ("curve", 9, 10), ("curve", 15, 10), ("curve", 18, 10), ("curve", 21, 10), ("bingham", 7, 0), ("bingham", 9, 0),
          ("vmf", 3, 6), ("vmf", 3, 8), ("vmf", 5, 5), ("vmf", 10, 3), ("vmf", 10, 10),
@@ -409,8 +411,8 @@ def test_large_dense_bingham_reads_A_from_global_memory(gs, oracle, d):
 
 def test_shape_limits(gs):
     """What the kernels are not built for is refused with a ValueError that names the limit, never a wrong
-    answer or a fault: d > 1024; target rows beyond a workgroup's LDS.  Just inside the limits everything runs (mode auto falls
-    back to the exact kernels where no fast kernel is built)."""
+    answer or a fault: d > 1024.  Inside the limit everything runs (mode auto falls back to the exact kernels where no fast
+    kernel is built)."""
     import warnings
 
     def run(pdf, d):
@@ -432,7 +434,10 @@ def test_shape_limits(gs):
     assert run(curve(10, 100), 10) == "exact" and run(curve(300, 18), 300) == "exact" and run(curve(512, 10), 512) == "fast"
     assert run(vmf(513, 3), 513) == "exact" and run(curve(1000, 10), 1000) == "exact" and run(vmf(1024, 2), 1024) == "exact"
     assert run(gs.random_bingham(d=600, vmax=20.0, vmin=0.0, eigensystem=True, seed=3), 600) == "exact"
-    for pdf, d, what in ((vmf(1025, 3), 1025, "max 1024"), (curve(2000, 10), 2000, "max 1024"), (curve(300, 60), 300, "of LDS"),
+    # target rows beyond a workgroup's LDS are read from global memory (round 4: 60 knots at d = 300, 40 components at d = 600,
+    # 9 000 components on S^2 were "target parameters need ... B of LDS" before)
+    assert run(curve(300, 60), 300) == "exact" and run(vmf(600, 40), 600) == "exact" and run(vmf(3, 9000), 3) == "exact"
+    for pdf, d, what in ((vmf(1025, 3), 1025, "max 1024"), (curve(2000, 10), 2000, "max 1024"),
                          (gs.random_bingham(d=1100, vmax=20.0, vmin=0.0, eigensystem=True, seed=3), 1100, "max 1024")):
         with pytest.raises(ValueError, match=what):
             run(pdf, d)
