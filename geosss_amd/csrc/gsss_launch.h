@@ -19,6 +19,7 @@ using VC16x8 = CoopVec<16, 8>;
 using VC64x4 = CoopVec<64, 4>;
 using VC64x8 = CoopVec<64, 8>;
 using VC64x16 = CoopVec<64, 16>;
+using VC64x32 = CoopVec<64, 32>;
 
 #define GSSS_VEC_LIST(X) \
     X(1, VL2, "lane2")       \
@@ -34,7 +35,8 @@ using VC64x16 = CoopVec<64, 16>;
     X(11, VC16x8, "coop16x8") \
     X(12, VC64x4, "coop64x4") \
     X(13, VC64x8, "coop64x8") \
-    X(14, VC64x16, "coop64x16")
+    X(14, VC64x16, "coop64x16") \
+    X(15, VC64x32, "coop64x32")
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 

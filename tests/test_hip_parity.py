@@ -310,7 +310,8 @@ SYNTH = [("vmf", 11, 6), ("vmf", 13, 4), ("vmf", 14, 2), ("vmf", 12, 7), ("vmf",
          ("bingham", 12, 0), ("bingham", 40, 0), ("bingham", 100, 0), ("bingham", 126, 0), ("bingham", 127, 0), ("bingham", 128, 0),
          # dense A beyond what LDS holds (d > 128): the exact kernels read its rows from global memory (Bingham<V>::Ag)
          ("bingham", 129, 0), ("bingham", 200, 0), ("bingham", 300, 0),
-         # d = 513 .. 1024: sixty-four lanes with sixteen slots each (round 4)
+         # d = 513 .. 2048: sixty-four lanes with sixteen / thirty-two slots each (round 4)
+         ("vmf", 1025, 4), ("curve", 2048, 10), ("bingham", 1100, 0),
          ("bingham", 600, 0), ("bingham_diag", 1024, 0), ("vmf", 513, 3), ("vmf", 1000, 12), ("curve", 700, 10), ("curve", 1024, 17),
          # target rows read from global memory: more components / knots than a workgroup's LDS holds at that d
          ("vmf", 600, 40), ("vmf", 3, 7000), ("curve", 300, 60), ("curve", 1000, 25), ("vmf", 100, 200), ("vmf", 16, 3), ("vmf", 50, 5), ("vmf", 200, 10), ("vmf", 7, 2), ("bingham", 24, 0), ("bingham", 3, 0),
@@ -411,7 +412,7 @@ def test_large_dense_bingham_reads_A_from_global_memory(gs, oracle, d):
 
 def test_shape_limits(gs):
     """What the kernels are not built for is refused with a ValueError that names the limit, never a wrong
-    answer or a fault: d > 1024.  Inside the limit everything runs (mode auto falls back to the exact kernels where no fast
+    answer or a fault: d > 2048.  Inside the limit everything runs (mode auto falls back to the exact kernels where no fast
     kernel is built)."""
     import warnings
 
@@ -437,8 +438,10 @@ def test_shape_limits(gs):
     # target rows beyond a workgroup's LDS are read from global memory (round 4: 60 knots at d = 300, 40 components at d = 600,
     # 9 000 components on S^2 were "target parameters need ... B of LDS" before)
     assert run(curve(300, 60), 300) == "exact" and run(vmf(600, 40), 600) == "exact" and run(vmf(3, 9000), 3) == "exact"
-    for pdf, d, what in ((vmf(1025, 3), 1025, "max 1024"), (curve(2000, 10), 2000, "max 1024"),
-                         (gs.random_bingham(d=1100, vmax=20.0, vmin=0.0, eigensystem=True, seed=3), 1100, "max 1024")):
+    assert run(vmf(1025, 3), 1025) == "exact" and run(curve(2000, 10), 2000) == "exact"
+    assert run(gs.random_bingham(d=1100, vmax=20.0, vmin=0.0, eigensystem=True, seed=3), 1100) == "exact"
+    for pdf, d, what in ((vmf(2049, 3), 2049, "max 2048"), (curve(3000, 10), 3000, "max 2048"),
+                         (gs.random_bingham(d=2100, vmax=20.0, vmin=0.0, eigensystem=True, seed=3), 2100, "max 2048")):
         with pytest.raises(ValueError, match=what):
             run(pdf, d)
 
