@@ -462,7 +462,7 @@ def test_edge_targets_match_oracle(gs, oracle_mod, case):
     import torch
     oracle = oracle_mod
     rng = np.random.default_rng(6000 + case)
-    d = int(rng.choice([3, 3, 4, 6, 8, 10, 12, 16, 24, 50, 130]))
+    d = int(rng.choice([3, 3, 4, 6, 8, 10, 12, 16, 24, 50, 130, 300, 700]))
     pdf, tgt, what = _edge_target(gs, oracle, rng, d)
     n, n_steps = (1500, 60) if d <= 16 else (300, 30)
     sampler = "reject" if rng.random() < 0.2 and "sharp" not in what else "shrink"
