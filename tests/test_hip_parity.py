@@ -648,8 +648,8 @@ def test_c_abi_argument_errors(gs):
     assert lib.gsss_target_create(C.byref(bad), 0, C.byref(out)) == -1
     ok = _lib.TargetDesc(1, 3, 2, 0, mu.ctypes.data, mu.ctypes.data, None, None, 0.0)
     assert lib.gsss_target_create(C.byref(ok), 99, C.byref(out)) == -4                    # no such device
-    eye = np.eye(2000)
-    big = _lib.TargetDesc(2, 2000, 0, 0, None, None, eye.ctypes.data, None, 0.0)
+    eye = np.eye(2100)
+    big = _lib.TargetDesc(2, 2100, 0, 0, None, None, eye.ctypes.data, None, 0.0)
     assert lib.gsss_target_create(C.byref(big), 0, C.byref(out)) == -2                    # d beyond every layout
     assert lib.gsss_target_dim(h) == 3 and lib.gsss_mode_supported(h, 1) == 1 and lib.gsss_mode_supported(h, 5) == 0
     assert lib.gsss_variant_name(h, 0, 0) == b"lane3" and lib.gsss_variant_name(h, 1, 0) == b"fast-lane"
