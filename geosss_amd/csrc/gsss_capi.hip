@@ -107,6 +107,32 @@ int select_vec(int d, int variant)
     return GSSS_E_UNSUPPORTED;
 }
 
+// The layout an exact-mode launch of this target runs in: select_vec's -- unless the target's rows (component means, knots, a
+// dense A) do not fit a workgroup's LDS in it: then the smallest sixty-four-lane layout, whose kernels read such rows from global
+// memory (rows_fit_lds, gsss_device.h).  A layout forced by the caller stays as asked.
+static int select_vec_for(const gsss::TargetBlock &tb, int variant)
+{
+    const int vec = select_vec(tb.d, variant);
+    if (vec < 0 || variant != 0) return vec;
+    int n;
+    const VecInfo *v = vec_table(&n);
+    size_t dpad = 0;
+    for (int i = 0; i < n; ++i)
+        if (v[i].id == vec) dpad = (size_t)v[i].dpad;
+    if (dpad >= 256) return vec;
+    size_t rows = 0;
+    switch (tb.kind) {
+    case GSSS_VMF_MIXTURE: rows = (size_t)tb.k * dpad + (size_t)tb.k; break;
+    case GSSS_BINGHAM: rows = (size_t)(tb.d + 1) * dpad; break;
+    case GSSS_CURVE_VMF: rows = (size_t)tb.k * dpad + 4 * (size_t)(tb.k - 1); break;
+    default: return vec;
+    }
+    if (rows * sizeof(double) <= gsss::kRowsLdsBytes) return vec;
+    for (int i = 0; i < n; ++i)
+        if (!v[i].exact_dim && v[i].dpad >= 256 && tb.d <= v[i].dpad) return v[i].id;
+    return vec;
+}
+
 // ------------------------------------------------------------------------------------------
 // device guard: HIP's current device is per host thread; leave it as we found it
 // ------------------------------------------------------------------------------------------
@@ -541,7 +567,7 @@ static int logprob_or_gradient(const gsss_target *t, const double *x_dev, int64_
         return GSSS_E_INVALID;
     }
     if (n == 0) return GSSS_OK;
-    const int vec = select_vec(t->tb.d, 0);
+    const int vec = select_vec_for(t->tb, 0);
     if (vec < 0) return vec;
     DeviceGuard guard(t->device);
     if (!guard.ok) return GSSS_E_HIP;
@@ -617,7 +643,7 @@ int gsss_run(const gsss_target *t, const gsss_run_args *a, void *stream)
         set_error("fast mode takes variant 0, GSSS_VARIANT_FAST_DOUBLE or GSSS_VARIANT_FAST_VERIFY");
         return GSSS_E_INVALID;
     }
-    const int vec = a->mode == GSSS_MODE_FAST ? 0 : select_vec(t->tb.d, a->variant);
+    const int vec = a->mode == GSSS_MODE_FAST ? 0 : select_vec_for(t->tb, a->variant);
     if (vec < 0) return vec;
     RunBlock rb{};
     rb.state = a->state_dev;
@@ -767,7 +793,7 @@ const char *gsss_variant_name(const gsss_target *t, int32_t mode, int32_t varian
         if (fast_dispatch(t->tb, RunBlock{}, false, &pr, nullptr) != GSSS_OK) return "";
         return pr.lane ? "fast-lane" : "fast-coop";
     }
-    const int vec = select_vec(t->tb.d, variant);
+    const int vec = select_vec_for(t->tb, variant);
     if (vec < 0) return "";
     int n;
     const VecInfo *v = vec_table(&n);

@@ -975,13 +975,18 @@ __device__ __forceinline__ void lds_fill(double *dst, int n_rows, int dpad, cons
     }
 }
 
+constexpr size_t kRowsLdsBytes = (size_t)136 * 1024;
 // Target rows (component means, knots) live in LDS, zero padded to the layout's DPAD -- or, where they do not fit a workgroup's
 // LDS (many components or knots at large d), are read from the parameter blob in global memory as they are (stride d): the same
 // products in the same order.  Host and device take the decision from (rows, DPAD) alone; 136 KB leave room for scratch and tables.
+// Only the sixty-four-lane layouts (DPAD >= 256) carry the global-memory path: the host runs a target whose rows do not fit the
+// LDS of its natural layout on the smallest of them (select_vec_for, gsss_capi.hip), and the kernels of the smaller layouts --
+// the ones whose speed matters in exact mode -- keep their code as it was (measured with a run-time choice in every layout:
+// 6 .. 20 % slower exact kernels at d <= 10).
 template <class V>
 __host__ __device__ constexpr bool rows_fit_lds(size_t doubles)
 {
-    return doubles * sizeof(double) <= (size_t)136 * 1024;
+    return V::DPAD < 256 || doubles * sizeof(double) <= kRowsLdsBytes;
 }
 // component c of a row: LDS rows are padded with zeros, global rows end at d
 template <bool GLOBAL, class V>
@@ -999,6 +1004,7 @@ struct VmfMixture {
     const double *mug;   // global [K][d]
     const double *logc;  // [K], LDS or global like the rows
     int K, d;
+    static constexpr bool kMayGlobal = V::DPAD >= 256;  // (rows_fit_lds)
 
     __host__ __device__ static bool in_lds(int k) { return rows_fit_lds<V>((size_t)k * V::DPAD + k); }
     __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return in_lds(k) ? (size_t)k * V::DPAD + k : 0; }
@@ -1034,7 +1040,7 @@ struct VmfMixture {
     }
     __device__ __forceinline__ double comp_logp(const double (&y)[V::N], int g, int k) const
     {
-        return mu != nullptr ? comp_logp_t<false>(y, g, k) : comp_logp_t<true>(y, g, k);
+        return (!kMayGlobal || mu != nullptr) ? comp_logp_t<false>(y, g, k) : comp_logp_t<true>(y, g, k);
     }
     // logsumexp_k( y.mu_k + logc_k )
     __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
@@ -1067,7 +1073,7 @@ struct VmfMixture {
     }
     __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
     {
-        if (mu != nullptr)
+        if (!kMayGlobal || mu != nullptr)
             grad_t<false>(y, g, out);
         else
             grad_t<true>(y, g, out);
@@ -1081,8 +1087,9 @@ struct Bingham {
     const double *Ag;  // ... or, where d^2 doubles do not fit in LDS (d > 128), the blob's own rows [d][d] in global memory (L2)
     const double *b;   // LDS [DPAD]: BinghamFisher linear term (zeros for a plain Bingham)
     int d;
+    static constexpr bool kMayGlobal = V::DPAD >= 256;  // (rows_fit_lds)
     // (host and device take the same decision from (d, DPAD): 136 KB leave room for the groups' scratch rows and the tables)
-    __host__ __device__ static bool in_lds(int d) { return (size_t)(d + 1) * V::DPAD * sizeof(double) <= (size_t)136 * 1024; }
+    __host__ __device__ static bool in_lds(int d) { return rows_fit_lds<V>((size_t)(d + 1) * V::DPAD); }
     __host__ __device__ static size_t lds_doubles(int /*k*/, int d) { return in_lds(d) ? (size_t)(d + 1) * V::DPAD : (size_t)V::DPAD; }
     __device__ void stage(double *lds, const TargetBlock &tb)
     {
@@ -1139,7 +1146,7 @@ struct Bingham {
             double xa[V::N];
 #pragma unroll
             for (int j = 0; j < V::N; ++j) xa[j] = 0.0;
-            if (Ag == nullptr) {
+            if (!kMayGlobal || Ag == nullptr) {
                 for (int i = 0; i < d; ++i) {
                     const double yi = scratch[i];
 #pragma unroll
@@ -1181,7 +1188,7 @@ struct Bingham {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int j = 0; j < V::N; ++j) out[j] = 0.0;
-            if (Ag == nullptr) {
+            if (!kMayGlobal || Ag == nullptr) {
                 for (int i = 0; i < d; ++i) {  // (A y)_j = sum_i A_ij y_i for the lane's own components j (A symmetric)
                     const double yi = scratch[i];
 #pragma unroll
@@ -1212,6 +1219,7 @@ struct CurveVmf {
     const double *seg;     // [K-1][4] : theta, cos(theta), sin(theta), sin(theta)+1e-10  (spherical_curve.py:28-31); LDS or global like the rows
     int K, d;
     double kappa;
+    static constexpr bool kMayGlobal = V::DPAD >= 256;  // (rows_fit_lds)
     __host__ __device__ static bool in_lds(int k) { return rows_fit_lds<V>((size_t)k * V::DPAD + 4 * (size_t)(k - 1)); }
     __host__ __device__ static size_t lds_doubles(int k, int /*d*/) { return in_lds(k) ? (size_t)k * V::DPAD + 4 * (size_t)(k - 1) : 0; }
     __device__ void stage(double *lds, const TargetBlock &tb)
@@ -1280,7 +1288,7 @@ struct CurveVmf {
     __device__ __forceinline__ double logp(const double (&y)[V::N], int g, double * /*scratch*/) const
     {
         auto nothing = [](const double (&)[V::N]) {};
-        return kappa * (knots != nullptr ? scan<false>(y, g, nothing) : scan<true>(y, g, nothing));
+        return kappa * ((!kMayGlobal || knots != nullptr) ? scan<false>(y, g, nothing) : scan<true>(y, g, nothing));
     }
     // distributions.py:277-278 : kappa * find_nearest(y)
     __device__ __forceinline__ void grad(const double (&y)[V::N], int g, double * /*scratch*/, double (&out)[V::N]) const
@@ -1291,7 +1299,7 @@ struct CurveVmf {
 #pragma unroll
             for (int i = 0; i < V::N; ++i) out[i] = kappa * near[i];
         };
-        if (knots != nullptr)
+        if (!kMayGlobal || knots != nullptr)
             (void)scan<false>(y, g, keep);
         else
             (void)scan<true>(y, g, keep);
