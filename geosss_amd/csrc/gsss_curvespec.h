@@ -41,6 +41,24 @@ namespace gsss {
 #ifndef GSSS_CS_WAVES_BIG
 #define GSSS_CS_WAVES_BIG 2
 #endif
+// Two or three component quads per lane, <= 10 knots: THREE wavefronts per SIMD with registers in scratch beat two without, while
+// the resident wavefronts' scratch stays in or near the L2 (384 wavefronts per XCD x 64 lanes x the bytes below; 4 MB of L2 per XCD,
+// the memory-side cache behind it).  Measured at 10^5 chains x 1000 steps, ms per launch (profiles/r04_ab_q2_three_waves.log):
+//   <4, 2, 10>  d = 17 .. 32     128 B a lane   d = 24: 26.45 -> 21.65 (+22 %; with the tangent parked in LDS too, 52 B: 21.8 -- not taken)
+//   <4, 3, 10>  d = 33 .. 48     224 B, tangent parked in LDS (264 B without: 25.8)   d = 40: 29.88 -> 25.46 (+17 %)
+//   <8, 3, 10>  d = 65 .. 96     148 B, parked (244 B: 43.7)                            d = 80: 47.33 -> 40.73 (+16 %)
+//   <16, 3, 10> d = 129 .. 192   200 B, parked (252 B: 79.2)                            d = 160: 86.49 -> 73.27 (+18 %)
+// Four quads lose: <4, 4, 10> 320 B (parked) d = 50: 32.46 -> 37.41; <8, 4, 10> 328 B d = 120: 54.45 -> 64.0; <16, 4, 10> 308 B
+// d = 200: 94.96 -> 110.6 -- they stay at two wavefronts, nothing spilled, the tangent in registers.
+#ifndef GSSS_CS_WAVES_Q2
+#define GSSS_CS_WAVES_Q2 3
+#endif
+#ifndef GSSS_CS_WAVES_Q3
+#define GSSS_CS_WAVES_Q3 3
+#endif
+#ifndef GSSS_CS_PARK_FROM_Q
+#define GSSS_CS_PARK_FROM_Q 99  // (A/B builds: component quads per lane from which every 10-knot build parks the tangent in LDS while the tries run)
+#endif
 #ifndef GSSS_CS_PACKED_BELOW
 #define GSSS_CS_PACKED_BELOW 64  // lanes per chain below which the screen evaluates two segments per packed instruction (Curve32<.., PACKED>):
                                  // every group size (sixteen lanes: packed with preloaded constants lost 1 %, packed without them and
@@ -71,7 +89,13 @@ __host__ __device__ constexpr int curvespec_scratch_doubles()
 template <int Q, int NK, bool HEAVY>
 __host__ __device__ constexpr bool curvespec_parks_u()
 {
-    return Q >= 2 && (NK > 10 || HEAVY);
+    return Q >= 2 && (NK > 10 || HEAVY || Q >= GSSS_CS_PARK_FROM_Q || (Q == 3 && GSSS_CS_WAVES_Q3 >= 3));
+}
+template <int L, int Q, int NK, bool STATS>
+__host__ __device__ constexpr int curvespec_waves()
+{
+    if (STATS || NK > 10) return GSSS_CS_WAVES_BIG;
+    return Q == 1 ? GSSS_CS_WAVES : (Q == 2 ? GSSS_CS_WAVES_Q2 : (Q == 3 ? GSSS_CS_WAVES_Q3 : GSSS_CS_WAVES_BIG));
 }
 template <int L, int Q, int NK, bool HEAVY>
 __host__ __device__ constexpr size_t curvespec_lds_doubles()
@@ -141,7 +165,7 @@ __device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &s
 }
 
 template <int L, int Q, int NK, bool REPLAY, bool STATS = false>
-__global__ void __launch_bounds__(kBlock, (Q == 1 && NK <= 10 && !STATS) ? GSSS_CS_WAVES : GSSS_CS_WAVES_BIG) curvespec_kernel(TargetBlock tb, RunBlock a)
+__global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
     using V = CoopVec<L, 4 * Q>;
     using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level

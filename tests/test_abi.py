@@ -198,14 +198,21 @@ def test_graft_entry_build_passes():
 
 
 def test_group_kernels_do_not_spill():
-    """The curve group kernels the bench times are built for three (d <= 16) / two wavefronts per SIMD WITHOUT scratch: their
+    """The curve group kernels the bench times are built for three (d <= 32) / two wavefronts per SIMD without scratch beyond a measured budget: their
     register budget rests on an internal LLVM option (geosss_amd/build.py probes it) and on the kernel's own structure, and a
     spilling build would send gigabytes of scratch traffic per launch to HBM (gsss_curvespec.h).  Checked from the compiler's
     own resource remarks, device code only (hipcc cross-compiles here)."""
     from geosss_amd import build
     ru = build.resource_usage("gsss_fast_curvespec.hip")
-    want = {"ILi4ELi1ELi10ELb0ELb0E": 3, "ILi16ELi1ELi10ELb0ELb0E": 3, "ILi4ELi2ELi10ELb0ELb0E": 2, "ILi4ELi4ELi10ELb0ELb0E": 2,
-            "ILi8ELi4ELi10ELb0ELb0E": 2, "ILi16ELi4ELi10ELb0ELb0E": 2}        # <L, Q, NK, replay, stats> -> waves per SIMD
+    want = {"ILi4ELi1ELi10ELb0ELb0E": 3, "ILi16ELi1ELi10ELb0ELb0E": 3, "ILi4ELi2ELi10ELb0ELb0E": 3, "ILi4ELi3ELi10ELb0ELb0E": 3,
+            "ILi8ELi3ELi10ELb0ELb0E": 3, "ILi16ELi3ELi10ELb0ELb0E": 3,
+            "ILi4ELi4ELi10ELb0ELb0E": 2, "ILi8ELi4ELi10ELb0ELb0E": 2, "ILi16ELi4ELi10ELb0ELb0E": 2}  # <L, Q, NK, replay, stats> -> waves per SIMD
+    # scratch a build may hold (bytes a lane).  Two and three component quads per lane are the MEASURED exceptions to "no
+    # scratch": three wavefronts with 128 .. 224 bytes spilled are 16-22 % faster than two without (gsss_curvespec.h,
+    # profiles/r04_ab_q2_three_waves.log; the resident wavefronts' scratch stays in or near the L2), which four quads are not
+    # (d = 50: 320 bytes, 15 % slower): those hold nothing in scratch
+    budget = {"ILi4ELi1ELi10ELb0ELb0E": 12, "ILi16ELi1ELi10ELb0ELb0E": 12, "ILi4ELi2ELi10ELb0ELb0E": 128, "ILi4ELi3ELi10ELb0ELb0E": 224,
+              "ILi8ELi3ELi10ELb0ELb0E": 148, "ILi16ELi3ELi10ELb0ELb0E": 200}
     seen = 0
     for name, r in ru.items():
         for key, waves in want.items():
@@ -214,7 +221,7 @@ def test_group_kernels_do_not_spill():
                 # (round 4: the d <= 16 build holds three dwords of step-invariant state in scratch since its segments are evaluated
                 # two at a time -- 12 bytes a lane, 5 MB per launch, L2-resident: 2 % faster than without; anything beyond that is a
                 # regression)
-                assert r["scratch"] <= (12 if waves == 3 else 0), (name, r)      # (the three-wavefront builds, <4,1,10> and <16,1,10>)
+                assert r["scratch"] <= budget.get(key, 0), (name, r)
                 assert r["occupancy"] >= waves, (name, r)
     assert seen == len(want), sorted(ru)
 
