@@ -50,6 +50,12 @@ namespace gsss {
 //   <16, 3, 10> d = 129 .. 192   200 B, parked (252 B: 79.2)                            d = 160: 86.49 -> 73.27 (+18 %)
 // Four quads lose: <4, 4, 10> 320 B (parked) d = 50: 32.46 -> 37.41; <8, 4, 10> 328 B d = 120: 54.45 -> 64.0; <16, 4, 10> 308 B
 // d = 200: 94.96 -> 110.6 -- they stay at two wavefronts, nothing spilled, the tangent in registers.
+// The 17-knot builds (curves of 11 .. 17 knots) likewise, one and two quads per lane (164 .. 208 B of scratch): 16 knots, 10^5 chains
+// x 1000 steps, <4,1,17> d = 10 34.5 -> 28.3 ms, <4,2,17> d = 24 36.7 -> 30.5, <16,2,17> d = 100 91.8 -> 77.0 (+19 .. 22 %); three quads
+// (<4,3,17>, 300 B) lose 6 % and stay at two.
+#ifndef GSSS_CS_WAVES_K17
+#define GSSS_CS_WAVES_K17 3
+#endif
 #ifndef GSSS_CS_WAVES_Q2
 #define GSSS_CS_WAVES_Q2 3
 #endif
@@ -94,7 +100,8 @@ __host__ __device__ constexpr bool curvespec_parks_u()
 template <int L, int Q, int NK, bool STATS>
 __host__ __device__ constexpr int curvespec_waves()
 {
-    if (STATS || NK > 10) return GSSS_CS_WAVES_BIG;
+    if (STATS) return GSSS_CS_WAVES_BIG;
+    if (NK > 10) return Q <= 2 ? GSSS_CS_WAVES_K17 : GSSS_CS_WAVES_BIG;
     return Q == 1 ? GSSS_CS_WAVES : (Q == 2 ? GSSS_CS_WAVES_Q2 : (Q == 3 ? GSSS_CS_WAVES_Q3 : GSSS_CS_WAVES_BIG));
 }
 template <int L, int Q, int NK, bool HEAVY>
