@@ -15,7 +15,10 @@ shrinkage sampler.  One bench "step" = one launch of the sampler kernel advancin
 states are resident in HBM before the timed region starts.  `value` = MCMC chain-steps per second over
 all GPUs.  After the headline timing, rank 0 of a single-GPU run also times <= ~1 s of each other
 BASELINE config (Bingham d=10, curve-vMF d=10/50/200, vMF mixture K=10 kappa=500) -> "configs".
-Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
+Rank 0 prints ONE compact JSON line (< 6 KB: numbers and short names; `compact_line`) as the LAST line of stdout and writes the
+complete record -- every field with its prose, per-config rooflines, ESS windows -- to bench_full.json (path in the line's
+`full_record`; DESIGN.md "Measurement" explains every field).  On a multi-GPU run every rank also times cfg5's own workload
+(vMF mixture K = 10 kappa = 500, 10^6 chains per GPU, chain ids rank * 10^6 ..., final gather) -> configs[{name: "..._sharded"}].
 """
 import argparse
 import json
@@ -45,6 +48,8 @@ EXTRA_CONFIGS = [("bingham_d10", 1_000_000), ("curve_d10", 100_000), ("curve_d50
 # ... and the headline target on NUMPY'S OWN STREAM (rng="numpy": PCG64 + ziggurat per chain, the reference's arithmetic and
 # draw order, mcmc.py:382-401 from the seed) -- the path that reproduces the reference's chains from (pdf, x0, seed) at 1e-10
 NUMPY_STREAM_CONFIG = ("vmfmix_readme", 1_000_000)
+# ... and, on a multi-GPU run, cfg5's own workload on every rank (10^6 chains per GPU, chain_offset = rank * 10^6, final gather)
+SHARDED_CONFIG = ("vmfmix_k10_kappa500", 1_000_000)
 
 
 def make_target(gs, name):
@@ -127,12 +132,20 @@ _digest = None
 
 
 def source_digest():
-    """sha256 of the kernel sources this tree was built from (geosss_amd.build.source_digest)."""
+    """sha256 of the kernel sources the LOADED libgsss_hip.so was built from (gsss_source_digest: embedded at build time).  The
+    library ships prebuilt, so the files on disk prove nothing about the binary that is timed; profiles are bound to the binary."""
     global _digest
     if _digest is None:
-        from geosss_amd import build
-        _digest = build.source_digest()
+        from geosss_amd import _lib
+        _digest = _lib.load().gsss_source_digest().decode()
     return _digest
+
+
+def tree_digest():
+    """The same sha256 over the files lying on disk (geosss_amd.build.source_digest); differs from source_digest() when the
+    library was built from other sources than the tree it sits in."""
+    from geosss_amd import build
+    return build.source_digest()
 
 
 def profile_record(workload, n, S, thin, mode, layout):
@@ -165,11 +178,11 @@ def issue_counters(workload, n, S, thin, mode, layout="chains"):
     return out
 
 
-def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms, layout="chains"):  # name: workload[__numpy_stream]
+def roofline_valu(name, d, tps, n, S, thin, mode, kern_ms, layout="chains"):  # name: workload[__numpy_stream][__all_double]
     """Delivered-work figure: the FP64 flops of the ALL-DOUBLE restricted-form algorithm whose decisions the kernel reproduces
     (algorithmic_flops) over the kernel time and the FP64 vector peak.  NOT a hardware utilisation: most per-try flops are
     executed in single precision; `fp64_issued_frac` and `valu_busy` are the hardware's own counters."""
-    flops = algorithmic_flops(name, d, tps, rng="numpy" if name.endswith("__numpy_stream") else "philox")
+    flops = algorithmic_flops(name, d, tps, rng="numpy" if "__numpy_stream" in name else "philox")
     out = {"bound": "fp64_valu", "achieved": flops * n * S / (kern_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
            "frac": flops * n * S / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "flops_per_chain_step": flops,
            "meaning": "algorithmic FP64 flops of the all-double algorithm / kernel time / FP64 vector peak: delivered work, not "
@@ -432,17 +445,18 @@ def numpy_stream_kernel_name(gs, sampler, packed_name):
     return name[:-1] + ", NUMPY>" if name.startswith("fast_kernel") else name
 
 
-def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="philox"):
+def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="philox", screen=True):
     """<= ~1 s of one of the other BASELINE configs: same launch shape as the headline workload.  rng="numpy": the same launch
-    on numpy's own stream, one generator per chain, packed (fast_kernel<..., NUMPY>)."""
+    on numpy's own stream, one generator per chain, packed (fast_kernel<..., NUMPY>).  screen=False: the all-double kernel
+    (GSSS_VARIANT_FAST_DOUBLE: every try decided in double precision, no single-precision screen)."""
     pdf, d = make_target(gs, name)
     x0 = gs.sample_sphere_device(d - 1, n, seed=0)
     kw_s = dict(rng="numpy", placement="packed") if rng == "numpy" else {}
-    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed, **kw_s)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed, screen=screen, **kw_s)
     thin = 100
     lib = gs._lib.load()
     mode_id = gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT
-    kernel = lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0, 1).decode()
+    kernel = lib.gsss_kernel_name(s._target_dev.handle, mode_id, 0 if screen else gs._lib.VARIANT_FAST_DOUBLE, 1).decode()
     if rng == "numpy":
         kernel = numpy_stream_kernel_name(gs, s, kernel)
     layout = pick_layout(layout, kernel, d, thin)
@@ -466,7 +480,7 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     tps = (int(s._n_tries.sum().item()) - tries0) / (n * S * reps)
     slice_steps, sliced_frac = last_slice_steps(gs)
-    wl_key = name + ("__numpy_stream" if rng == "numpy" else "")
+    wl_key = name + ("__numpy_stream" if rng == "numpy" else "") + ("" if screen else "__all_double")
     traffic, src = measured_traffic(wl_key, n, S, thin, s.mode, layout)
     value = n * S * reps / dt
     # ESS / s of the whole ensemble from the running lag sums: thin so that ~64 lags span the autocorrelation (slow targets: Bingham)
@@ -478,8 +492,10 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="
         # not long enough; it stays in the line as `one_window`, the doubling windows replace it)
         ess_out["between_chains_one_window"] = ess_out.pop("between_chains")
         ess_out["between_chains"] = ess_between_chains_doubling(gs, torch, s, pdf, name, value)
-    return {"workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}"
-                        + (", rng=numpy (one PCG64 generator per chain), packed" if rng == "numpy" else ""),
+    return {"name": wl_key,
+            "workload": f"{name}: shrinkage slice sampler, {n} chains x {S} transitions per launch, thin={thin}"
+                        + (", rng=numpy (one PCG64 generator per chain), packed" if rng == "numpy" else "")
+                        + ("" if screen else ", screen=False (all-double kernel)"),
             "stream": STREAM_NUMPY if rng == "numpy" else stream_description(d), "slice_steps": slice_steps,
             "sliced_fraction": round(sliced_frac, 4),
             "value": value, "unit": "chain-steps/s", "launches": reps, "mode": s.mode, "ess": ess_out,
@@ -488,6 +504,144 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="
             "roofline": hbm_roofline(d, thin, S, n, kern_ms, slice_steps, sliced_frac, traffic, src),
             "kept_rows_layout": layout,
             "roofline_valu": roofline_valu(wl_key, d, tps, n, S, thin, s.mode, kern_ms, layout)}
+
+
+def time_sharded_config(gs, torch, dist, name, n, S, rank, world, barrier, gather_states, seed=3521, thin=100):
+    """Another BASELINE config timed on EVERY rank of a multi-GPU run (cfg5: vMF mixture K = 10 kappa = 500, 10^6 chains per GPU,
+    chain ids rank * 10^6 ..., final states gathered: SURVEY.md section 8(d)/(e); the reference's fan-out of independent
+    processes, scripts/mixture_vMF.py:137-149).  Same bracketing as the headline: barrier + synchronize on both sides, the gather
+    inside the timed region, max over ranks."""
+    pdf, d = make_target(gs, name)
+    x0 = gs.sample_sphere_device(d - 1, n, seed=0, chain_offset=rank * n)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed, chain_offset=rank * n)
+    lib = gs._lib.load()
+    kernel = lib.gsss_kernel_name(s._target_dev.handle, gs._lib.MODE_FAST if s.mode == "fast" else gs._lib.MODE_EXACT, 0, 1).decode()
+    layout = pick_layout("auto", kernel, d, thin)
+    kept, kw = kept_buffer(torch, layout, n, S, thin, d)
+    counts = [n] * world
+    s.advance(100)                                   # warm-up: 100 transitions
+    gather_states(s.state_device, counts=counts)
+    reps = 5
+    tries0 = int(s._n_tries.sum().item())
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        s.advance(S, thin=thin, out=kept, **kw)
+        b.record()
+    g0.record()
+    final = gather_states(s.state_device, counts=counts)
+    g1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ones = torch.ones(1, dtype=torch.int64, device="cuda")
+    agg = torch.tensor([int(s._n_tries.sum().item()) - tries0, int((s._err != 0).sum().item())], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ones)
+        dist.all_reduce(agg)
+    assert final.shape[1] == n * world
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    total = n * S * reps * world
+    return {"name": name + "_sharded", "workload": f"{name}: {n} chains per GPU x {S} transitions per launch, thin={thin}, chain ids "
+                                                   f"rank * {n} ..., final states gathered, {world} ranks",
+            "value": total / float(tmax.item()), "unit": "chain-steps/s", "launches": reps, "kernel": kernel, "kernel_ms": kern_ms,
+            "gather_ms": float(g0.elapsed_time(g1)), "ranks_seen": int(ones.item()), "tries_per_step": int(agg[0].item()) / total,
+            "chains_in_error": int(agg[1].item()), "kept_rows_layout": layout,
+            "roofline": hbm_roofline(d, thin, S, n, kern_ms, *last_slice_steps(gs), None, "counters: not collected on a multi-rank run")}
+
+
+def _num(v, digits=6):
+    """Floats of the printed line at 6 significant digits (the full record keeps every digit)."""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: _num(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+LINE_LIMIT = 6000  # bytes: the driver reads the LAST stdout line out of an 8 KB tail (round 4's 34.7 KB line was not parsed)
+
+
+def compact_line(full, full_path=None):
+    """The ONE JSON line bench.py prints: numbers and short names only, every prose field (the `*_meaning`, `note`,
+    `estimator`, stream descriptions) and the per-config detail stay in the full record (bench_full.json; DESIGN.md section 6/7
+    explains each field).  configs[] = [{name, value, kernel_ms, hbm_frac, valu_frac, traffic_ratio}]."""
+    cfg = full["config"]
+    out = _pick(full, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"])
+    out["config"] = _pick(cfg, ["workload", "target", "d", "chains_per_gpu", "transitions_per_step", "thin", "mode", "kernel",
+                                "kept_rows_layout", "slice_steps", "sliced_fraction", "csrc_sha256", "library_matches_tree"])
+    out["config"]["stream"] = cfg["stream_short"]
+    by_name = {c["name"]: c for c in full.get("configs", [])}
+    # the same target, launch shape and sampler (a) on numpy's own stream = the reference's arithmetic and draw order,
+    # mcmc.py:382-401 from the seed; (b) in the all-double kernel (no single-precision screen)
+    out["value_numpy_stream"] = by_name.get(cfg["target"] + "__numpy_stream", {}).get("value")
+    out["value_all_double"] = by_name.get(cfg["target"] + "__all_double", {}).get("value")
+    out.update(_pick(full, ["tries_per_step", "chains_in_error", "kernel_ms"]))
+    out["roofline"] = _pick(full["roofline"], ["bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes", "handover_bytes",
+                                               "traffic", "traffic_ratio"])
+    src = full["roofline"].get("traffic_source") or ""
+    out["roofline"]["traffic_source"] = src.split(" (")[0][:80]
+    out["roofline_valu"] = _pick(full["roofline_valu"], ["bound", "achieved", "peak", "unit", "frac", "flops_per_chain_step",
+                                                         "fp64_issued_frac", "valu_busy", "resident_waves_per_simd",
+                                                         "valu_insts_per_chain_step", "lane_activity"])
+    out["roofline_valu"]["counters"] = "profiles/traffic.json" if full["roofline_valu"].get("valu_busy") is not None else \
+        str(full["roofline_valu"].get("counters"))[:40]
+    if full.get("cpu_baseline"):
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
+        out["cpu_baseline"]["sample"] = cb["sample"].split(" of the same")[0] + f", C oracle, {cb['cores']} threads"
+        if cb.get("numpy_port"):
+            out["cpu_baseline"]["numpy_port_1_core"] = cb["numpy_port"]["steps_per_s_1_core"]
+        if cb.get("reference"):
+            out["cpu_baseline"]["reference_1_core_build_container"] = cb["reference"]["steps_per_s_1_core"]
+    if full.get("ess"):
+        e = full["ess"]
+        out["ess"] = {"ess_per_step": e["ess_per_step"], "ess_per_sec": e["ess_per_sec"],
+                      "tau_steps_between_chains": e["between_chains"]["tau_steps"]}
+    r = full.get("rccl") or {}
+    out["rccl"] = _pick(r, ["ranks_seen", "backend", "gather_ms"])
+    if "kernel_ms_per_rank" in r:
+        out["rccl"]["kernel_ms_min_max"] = [r["kernel_ms_per_rank"]["min"], r["kernel_ms_per_rank"]["max"]]
+        out["rccl"]["wall_ms_min_max"] = [r["wall_ms_per_rank"]["min"], r["wall_ms_per_rank"]["max"]]
+    rows = []
+    for c in full.get("configs", []):
+        row = {"name": c["name"], "value": c["value"], "kernel_ms": c["kernel_ms"], "hbm_frac": c["roofline"]["frac"],
+               "valu_frac": (c.get("roofline_valu") or {}).get("frac"), "traffic_ratio": c["roofline"].get("traffic_ratio")}
+        row.update(_pick(c, ["gather_ms", "ranks_seen"]))
+        rows.append(row)
+    out["configs"] = rows
+    if full_path:
+        out["full_record"] = full_path
+    line = json.dumps(_num(out), separators=(",", ":"))
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def write_full_record(full):
+    """The complete record (every field of rounds 1-4's line and more) beside the printed line: ./bench_full.json, and under
+    gpurun_out/ too when that directory exists (it is what travels back from a GPU box)."""
+    path = None
+    for cand in (os.path.join(ROOT, "gpurun_out", "bench_full.json"), os.path.join(ROOT, "bench_full.json")):
+        try:
+            if os.path.isdir(os.path.dirname(cand)):
+                with open(cand, "w") as f:
+                    json.dump(full, f, indent=1)
+                path = path or os.path.relpath(cand, ROOT)
+        except OSError:
+            pass
+    return path
+
 
 
 def main(argv=None):
@@ -610,6 +764,7 @@ def main(argv=None):
     assert final.shape[1] == n * world
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    headline_slices = last_slice_steps(gs)
     if world > 1:  # per-rank kernel time and this rank's own wall clock: imbalance between GPUs shows in the line
         mine = torch.tensor([kern_ms, (time.perf_counter() - t0) * 1e3], dtype=torch.float64, device="cuda")
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
@@ -628,8 +783,13 @@ def main(argv=None):
     total_steps = chain_steps * world
     value = total_steps / elapsed
 
+    sharded = None
+    if world > 1 and not args.no_configs and args.workload == "vmfmix_readme":
+        del kept                                      # every rank: cfg5's own workload, sharded like the headline
+        sharded = time_sharded_config(gs, torch, dist, *SHARDED_CONFIG, S, rank, world, barrier, gather_states)
+
     if rank == 0:
-        slice_steps, sliced_frac = last_slice_steps(gs)
+        slice_steps, sliced_frac = headline_slices
         lib = gs._lib.load()
         mode_id = gs._lib.MODE_FAST if sampler.mode == "fast" else gs._lib.MODE_EXACT
         traffic, traffic_src = measured_traffic(wl_key, n, S, thin, sampler.mode, layout)
@@ -638,12 +798,16 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: shrinkage slice sampler, {n} chains/GPU x {S} transitions per "
-                                   "launch, thin=%d, Philox4x32-10 stream (philox-v2)" % thin,
+                                   "launch, thin=%d" % thin,
                        "stream": STREAM_NUMPY if args.rng == "numpy" else stream_description(d),
-                       "target": wl_key, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "slice_steps": slice_steps,
-                       "sliced_fraction": round(sliced_frac, 4),
+                       "stream_short": "numpy PCG64+ziggurat per chain (mcmc.py:387-395 order)" if args.rng == "numpy" else (
+                           "philox-v2 (chain,step)-keyed; S2: tangent = one 32-bit angle" if d == 3 else
+                           "philox-v2 (chain,step)-keyed; f32 Box-Muller normals, 53-bit uniforms"),
+                       "target": wl_key, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "thin": thin,
+                       "slice_steps": slice_steps, "sliced_fraction": round(sliced_frac, 4),
                        "kept_rows_layout": layout,
-                       "csrc_sha256": source_digest(),
+                       "csrc_sha256": source_digest(),           # of the LOADED library (gsss_source_digest)
+                       "library_matches_tree": source_digest() == tree_digest(),
                        "mode": sampler.mode,
                        "kernel": (numpy_stream_kernel_name(gs, sampler, lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, 0, 1).decode())
                                   if args.rng == "numpy" else lib.gsss_kernel_name(sampler._target_dev.handle, mode_id, args.variant, 1).decode()),
@@ -663,9 +827,12 @@ def main(argv=None):
             del sampler, kept
             out["configs"] = [time_config(gs, torch, name, nc, S, layout=args.layout) for name, nc in EXTRA_CONFIGS]
             out["configs"].append(time_config(gs, torch, *NUMPY_STREAM_CONFIG, S, layout=args.layout, rng="numpy"))
+            out["configs"].append(time_config(gs, torch, *NUMPY_STREAM_CONFIG, S, layout=args.layout, screen=False, ess=False))
+        if sharded is not None:
+            out["configs"] = [sharded]
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, write_full_record(out)), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0

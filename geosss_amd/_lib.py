@@ -12,7 +12,7 @@ MODE_EXACT, MODE_FAST = 0, 1
 VARIANT_FAST_DOUBLE = 100
 VARIANT_FAST_VERIFY = 101
 CHAIN_MAX_TRIES, CHAIN_NONFINITE, CHAIN_REPLAY_EXHAUSTED, CHAIN_COUNTER_SATURATED = 1, 2, 4, 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 STATS_NO_SECOND_MOMENT = 1
 
 
@@ -48,6 +48,7 @@ class RunArgs(C.Structure):
 SIGNATURES = {
     "gsss_abi_version": (C.c_int, []),
     "gsss_last_error": (C.c_char_p, []),
+    "gsss_source_digest": (C.c_char_p, []),
     "gsss_device_count": (C.c_int, []),
     "gsss_target_create": (C.c_int, [C.POINTER(TargetDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "gsss_target_destroy": (C.c_int, [C.c_void_p]),
@@ -62,6 +63,8 @@ SIGNATURES = {
     "gsss_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "gsss_sample_sphere": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "gsss_tangent_s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
+    "gsss_screen_constants": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
+    "gsss_f32_error_sweep": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
     "gsss_rows_to_components": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),
     "gsss_components_to_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),
     "gsss_samples_to_chains": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int, C.c_void_p]),

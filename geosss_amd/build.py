@@ -65,17 +65,28 @@ def headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+DIGEST_SOURCE = "gsss_digest.hip"  # carries source_digest() of the whole tree into the library (gsss_source_digest)
+
+
 def compile_one(src, force, extra, obj_dir=OBJ):
     obj = os.path.join(obj_dir, src[:-4] + ".o")
     path = os.path.join(CSRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), headers_mtime()):
+    defines, stamp = [], None
+    if src == DIGEST_SOURCE:  # rebuilt whenever ANY kernel source moved: the digest it embeds is that of all of them
+        digest = source_digest()
+        defines, stamp = [f'-DGSSS_SOURCE_DIGEST="{digest}"'], obj + ".digest"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+            return obj, False
+    elif not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), headers_mtime()):
         return obj, False
-    cmd = [hipcc(), *CXXFLAGS, *source_flags(src), *extra, "-c", path, "-o", obj]
+    cmd = [hipcc(), *CXXFLAGS, *source_flags(src), *defines, *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    if stamp:
+        open(stamp, "w").write(defines[0].split('"')[1])
     return obj, True
 
 

@@ -37,22 +37,31 @@ int64_t resident_workgroups(const void *kern, size_t lds_bytes, int *per_cu_out)
         (void)hipGetLastError();
         return 0;
     }
+    // GSSS_RESIDENT_PER_CU (tests): plan the launch as if the chip held this many workgroups of the kernel per CU -- the sliced
+    // shapes of another box reproduced on this one.  Safe for any value: a slice waits only for workgroups that drew their ticket
+    // before it (SliceSched), whatever the plan assumed to be resident.  Read per call, never cached.
+    const char *env = getenv("GSSS_RESIDENT_PER_CU");
+    const int forced = env ? atoi(env) : 0;
+    int per_cu = 0, cus = 0;
     {
         std::lock_guard<std::mutex> lock(mu);
         for (const Entry &e : cache)
             if (e.kern == kern && e.lds == lds_bytes && e.dev == dev) {
-                if (per_cu_out) *per_cu_out = e.per_cu;
-                return (int64_t)e.per_cu * e.cus;
+                per_cu = e.per_cu;
+                cus = e.cus;
+                break;
             }
     }
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-        (void)hipGetLastError();
-        return 0;
+    if (per_cu < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes) != hipSuccess || per_cu < 1 ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        cache.push_back(Entry{kern, lds_bytes, dev, per_cu, cus});
     }
-    std::lock_guard<std::mutex> lock(mu);
-    cache.push_back(Entry{kern, lds_bytes, dev, per_cu, cus});
+    if (forced > 0) per_cu = forced;
     if (per_cu_out) *per_cu_out = per_cu;
     return (int64_t)per_cu * cus;
 }

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "gsss_fast.h"
+#include "gsss_screen_consts.h"
 
 #ifndef GSSS_VMF_ONE_BUILD
 #define GSSS_VMF_ONE_BUILD 1  // (0: without the one-chain-per-lane build of the K = 7 .. 10 mixtures, A/B)
@@ -45,13 +46,6 @@ namespace gsss {
 enum : int32_t { kFinalAccept = 3, kFinalDecide = 4, kFinalInHi = 2 };
 __device__ __forceinline__ bool is_final(int32_t st) { return st >= kFinalAccept; }
 __device__ __forceinline__ bool is_decide(int32_t st) { return st == kFinalDecide || st == kFinalDecide + kFinalInHi; }
-
-// |v_cos_f32(fl32(theta / 2 pi)) - cos(theta)| for |theta| <= 2 pi: 1.254e-7 from the hardware (exhaustive sweep)
-// + 2 pi 2^-25 from rounding the argument (in revolutions, |t| <= 1) to single precision; same for sin
-constexpr float kSinCosErr32 = 3.5e-7f;
-constexpr float kUnit32 = 5.9604645e-8f;  // 2^-24
-constexpr float kExp2Err32 = 8.5e-8f;     // relative error of v_exp_f32 on normal results (exhaustive sweep)
-constexpr float kLog2Err32 = 1.3e-7f;     // log2 of a double via frexp + v_log_f32 of the mantissa rounded to single
 
 __device__ __forceinline__ void sincos_rev32(double theta, float &s, float &c)
 {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSSS_ABI_VERSION 9
+#define GSSS_ABI_VERSION 10
 
 /* target families (geosss/distributions.py) */
 #define GSSS_VMF_MIXTURE 1 /* MixtureModel of VonMisesFisher  :117-160, :209-227 */
@@ -222,6 +222,11 @@ typedef struct gsss_run_args {
 int gsss_abi_version(void);
 const char *gsss_last_error(void);
 
+/* sha256 (hex) over the kernel sources this library was BUILT from (the .h, .hip and .inc files of geosss_amd/csrc and this header, by name:
+ * geosss_amd/build.py source_digest), "unknown" for a build that did not pass it.  Profiles are bound to the binary through it:
+ * bench.py quotes the committed rocprofv3 counters only for the digest of the loaded library.  Nothing in the reference. */
+const char *gsss_source_digest(void);
+
 /* number of visible gfx950 devices (0 if none); does not fail */
 int gsss_device_count(void);
 
@@ -281,6 +286,24 @@ int gsss_sample_sphere(uint64_t seed, uint64_t chain_offset, int64_t n, int32_t 
  * tests/test_hip_tangent.py holds it to the reference's own tangents (tests/golden/tangent_kat.npz). */
 int gsss_tangent_s2(const double *x_dev, const uint32_t *w_dev, int64_t n, int32_t table_driven, double *out_dev, int device,
                     void *stream);
+
+/* Verification of the single-precision screen.  In fast mode four tries out of five are decided on the hardware's
+ * single-precision sin / cos / 2^x / log2 / sqrt with an error margin; the decision protected is
+ * mcmc.py:397 `if p(y) > threshold`, and it is the double-precision one only if each instruction's worst-case error is inside the
+ * constant the margin is built from.  gsss_screen_constants: out[0..5) = the constants compiled into the library --
+ * kSinCosErr32 (|v_sin/cos_f32(fl32(theta / 2 pi)) - sin/cos(theta)|, |theta| <= 2 pi, argument rounding included), kExp2Err32
+ * (relative, normal results), kLog2Err32 (log2 of a double's mantissa, its rounding to single included), kSqrtRelErr32, 2^-24.
+ * gsss_f32_error_sweep: evaluates EVERY float of an instruction's argument range on `device` against double precision
+ * (synchronous; ~1 s) and writes four maxima to out_host:
+ *   which 0  sin / cos of t revolutions, every |t| <= 1:   [0] sin, [1] cos at the float; [2], [3] with 2 pi x half an ulp of t added
+ *                                                           (any theta whose revolutions round to t) -- to hold against kSinCosErr32
+ *   which 1  2^x, every finite float:                       [0] relative error on normal results (kExp2Err32), [1] absolute error where
+ *                                                           the result is below the normals, [2] overflows not returned as +inf (0)
+ *   which 2  log2 x, every float of [0.5, 2]:               [0] at the float, [1] on [0.5, 1] with half an ulp / (x ln 2) added (kLog2Err32)
+ *   which 3  sqrt x, every positive normal float:           [0] relative error (kSqrtRelErr32)
+ * n_swept_out (may be NULL): how many floats were evaluated.  tests/test_hip_screen_bounds.py.  Nothing in the reference. */
+int gsss_screen_constants(double *out, int32_t n);
+int gsss_f32_error_sweep(int32_t which, double *out_host, uint64_t *n_swept_out, int device, void *stream);
 
 /* Layout changes between numpy's row-major arrays and the component-major device layout.
  *   gsss_rows_to_components: in [n][d]            -> out [d][n]

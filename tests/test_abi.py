@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in gsss.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.gsss_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.gsss_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_header():
