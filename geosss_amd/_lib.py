@@ -72,6 +72,9 @@ SIGNATURES = {
     "gsss_free": (C.c_int, [C.c_void_p, C.c_int]),
     "gsss_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "gsss_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "gsss_malloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),
+    "gsss_free_host": (C.c_int, [C.c_void_p]),
+    "gsss_memcpy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "gsss_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),
     "gsss_stream_synchronize": (C.c_int, [C.c_int, C.c_void_p]),
 }

@@ -925,6 +925,33 @@ int gsss_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int devic
     return GSSS_OK;
 }
 
+int gsss_malloc_host(void **out_host, size_t bytes, int device)
+{
+    if (!out_host) {
+        set_error("null argument");
+        return GSSS_E_INVALID;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipHostMalloc(out_host, bytes ? bytes : 1, hipHostMallocDefault));
+    return GSSS_OK;
+}
+
+int gsss_free_host(void *p_host)
+{
+    if (!p_host) return GSSS_OK;
+    GSSS_HIP_TRY(hipHostFree(p_host));
+    return GSSS_OK;
+}
+
+int gsss_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return GSSS_OK;
+}
+
 int gsss_memset(void *dst_dev, int value, size_t bytes, int device, void *stream)
 {
     DeviceGuard guard(device);

@@ -32,7 +32,10 @@ import warnings
 import numpy as np
 import torch
 
-from . import _lib
+import contextlib
+import os
+
+from . import _lib, _pinned
 from .sphere import _device_index, current_stream_ptr
 
 __all__ = ["determine_burnin", "RejectionSphericalSliceSampler", "ShrinkageSphericalSliceSampler", "MetropolisHastings",
@@ -40,6 +43,11 @@ __all__ = ["determine_burnin", "RejectionSphericalSliceSampler", "ShrinkageSpher
 
 _MODES = {"exact": _lib.MODE_EXACT, "fast": _lib.MODE_FAST, "auto": None}
 _MAX_STEPS_PER_LAUNCH = 4096
+# sample() -> ndarray: below this many bytes the array is copied in one piece; above, blocks of chains are sampled and copied in a
+# pipeline (the copy of block k under the kernel of block k + 1)
+_PIPELINE_MIN_BYTES = 64 << 20
+_COPY_GBS = 45.0          # what a device-to-host copy into page-locked memory sustains (planning figure for the number of blocks)
+_ROUND_STEP_S = 16e-6     # one transition of one resident round of workgroups (README mixture: 15 us; planning figure)
 
 
 def determine_burnin(n_samples, burnin):
@@ -493,13 +501,19 @@ class RejectionSphericalSliceSampler:
         self._sync_rng()
         return self.state
 
-    def sample(self, n_samples, burnin=0, return_all_samples=False, *, thin=1, as_tensor=False):
+    def sample(self, n_samples, burnin=0, return_all_samples=False, *, thin=1, as_tensor=False, blocks=None):
         """Markov chain(s) of the desired size (mcmc.py:55-77): the initial state is row 0 of the
         chain, `n_samples + burnin - 1` transitions are simulated, the first `burnin` rows are
         dropped unless return_all_samples.  One chain -> (n_samples, d); many -> (n_chains, n_samples, d).
 
         Extensions: thin=t keeps every t-th of the transitions after burn-in (row 0 stays the
         post-burn-in state); as_tensor=True returns a CUDA tensor instead of a numpy array.
+
+        The ndarray is returned at the speed of the PCIe link: it lives in page-locked host memory (geosss_amd/_pinned.py) and,
+        when it is large, the ensemble is sampled in `blocks` contiguous blocks of chains -- a block's rows are one contiguous
+        run of the (chains, draws, dims) array -- so that the copy of block k runs under the kernel of block k + 1.  The
+        streams are keyed by global chain id (or are one generator per chain): the result does not depend on `blocks`
+        (None: chosen from the sizes; 1: one launch sequence for all chains, as `as_tensor=True` always does).
         """
         if not n_samples > 0:
             raise AssertionError("n_samples must be positive")  # mcmc.py:62
@@ -507,10 +521,20 @@ class RejectionSphericalSliceSampler:
         n_rows = n_samples + burnin if return_all_samples else n_samples
         skip = 0 if return_all_samples else burnin
         steps0 = self._step
+        if as_tensor:
+            out = torch.empty((self.n_chains, n_rows, self.d), dtype=torch.float64, device=self._tdev)
+            self._sample_rows(out, skip, n_rows, thin)
+        else:
+            out = self._sample_to_host(skip, n_rows, thin, blocks)
+        self._account_calls(self._step - steps0)
+        self._check_errors()
+        self._sync_rng()
+        return out[0] if self._single else out
+
+    def _sample_rows(self, out, skip, n_rows, thin):
+        """burn-in, row 0 = the state after it, then the kept rows, written straight into `out` (chains, draws, dims)."""
         if skip:
             self.advance(skip)
-        # the kernels write straight into the reference's (chains, draws, dims) order
-        out = torch.empty((self.n_chains, n_rows, self.d), dtype=torch.float64, device=self._tdev)
         out[:, 0, :] = self.state_rows()
         self._begin_sample_buffer(out)     # (samplers that keep further per-draw rows lay them out like `out`: _launch_extra)
         try:
@@ -518,12 +542,80 @@ class RejectionSphericalSliceSampler:
                 self.advance((n_rows - 1) * thin, thin=thin, out=out, chain_major=True, row0=1)
         finally:
             self._sample_buffer = None
-        self._account_calls(self._step - steps0)
-        self._check_errors()
-        self._sync_rng()
-        if self._single:
-            out = out[0]
-        return out if as_tensor else out.cpu().numpy()
+
+    _blockwise = True   # (samplers with further per-chain launch arguments sample all chains in one launch sequence)
+
+    def _plan_blocks(self, skip, n_rows, thin, blocks):
+        """How many blocks of chains sample() -> ndarray runs.  The copy is the long pole (10^6 chains x 100 rows on S^2: 2.4 GB,
+        ~50 ms; the kernel: 2.5 ms), so as many blocks as keep the sum of the blocks' kernel times -- a block that does not
+        fill the chip still takes a resident round's time per transition -- inside the copy time."""
+        n = self.n_chains
+        nbytes = 8 * n * n_rows * self.d
+        if blocks is None:
+            env = os.environ.get("GSSS_SAMPLE_BLOCKS")
+            blocks = int(env) if env else None
+        if blocks is None:
+            if nbytes < _PIPELINE_MIN_BYTES or not self._blockwise or self._stats is not None:
+                return 1
+            copy_s = nbytes / (_COPY_GBS * 1e9)
+            block_s = (skip + (n_rows - 1) * thin) * _ROUND_STEP_S
+            blocks = int(min(16, nbytes // (32 << 20), copy_s / max(block_s, 1e-6)))
+        blocks = max(1, min(int(blocks), n))
+        if blocks > 1 and (not self._blockwise or self._stats is not None):
+            raise ValueError("this sampler carries per-chain launch state beyond the slice samplers': blocks must be 1")
+        return blocks
+
+    @contextlib.contextmanager
+    def _chain_block(self, c0, c1, step):
+        """The sampler restricted to chains c0 .. c1 - 1 at stream position `step`: counters and generator states are views, the
+        states a compact [d, m] copy written back on exit (the kernels index state[j * n_chains + c])."""
+        keep = (self._state, self.n_chains, self.chain_offset, self._n_reject, self._n_tries, self._err, self._rng_state, self._step)
+        sub = self._state[:, c0:c1].contiguous()
+        self._state, self.n_chains, self.chain_offset = sub, c1 - c0, keep[2] + c0
+        self._n_reject, self._n_tries, self._err = keep[3][c0:c1], keep[4][c0:c1], keep[5][c0:c1]
+        self._rng_state = None if keep[6] is None else keep[6][c0:c1]
+        self._step = step
+        try:
+            yield
+            step_end = self._step
+        finally:
+            (self._state, self.n_chains, self.chain_offset, self._n_reject, self._n_tries, self._err, self._rng_state, self._step) = keep
+        self._state[:, c0:c1] = sub
+        self._step = step_end
+
+    def _sample_to_host(self, skip, n_rows, thin, blocks):
+        n, d = self.n_chains, self.d
+        blocks = self._plan_blocks(skip, n_rows, thin, blocks)
+        host = _pinned.empty((n, n_rows, d), self.device)
+        lib, dev = self._lib, self.device
+        main = torch.cuda.current_stream(dev)
+        if blocks == 1:
+            out = torch.empty((n, n_rows, d), dtype=torch.float64, device=self._tdev)
+            self._sample_rows(out, skip, n_rows, thin)
+            _lib.check(lib.gsss_memcpy_d2h_async(host.ctypes.data, out.data_ptr(), host.nbytes, dev, main.cuda_stream))
+            main.synchronize()
+            return host
+        per = -(-n // blocks)
+        bufs = [torch.empty((per, n_rows, d), dtype=torch.float64, device=self._tdev) for _ in range(2)]
+        copy = torch.cuda.Stream(dev)
+        copied = [None, None]                       # the event after which a buffer may be written again
+        step0, row_bytes = self._step, 8 * n_rows * d
+        for k, c0 in enumerate(range(0, n, per)):
+            c1 = min(n, c0 + per)
+            buf = bufs[k % 2][:c1 - c0]
+            if copied[k % 2] is not None:
+                main.wait_event(copied[k % 2])
+            with self._chain_block(c0, c1, step0):
+                self._sample_rows(buf, skip, n_rows, thin)
+            done = torch.cuda.Event()
+            done.record(main)
+            copy.wait_event(done)
+            _lib.check(lib.gsss_memcpy_d2h_async(host.ctypes.data + c0 * row_bytes, buf.data_ptr(), (c1 - c0) * row_bytes, dev, copy.cuda_stream))
+            copied[k % 2] = torch.cuda.Event()
+            copied[k % 2].record(copy)
+        copy.synchronize()
+        main.synchronize()
+        return host
 
 
 class ShrinkageSphericalSliceSampler(RejectionSphericalSliceSampler):
@@ -539,6 +631,8 @@ class MetropolisHastings(RejectionSphericalSliceSampler):
 
     _sampler = _lib.RWMH
     _calls_per_step = 2  # log_prob(proposal) and log_prob(state), mcmc.py:152
+
+    _blockwise = False  # (per-chain stepsizes, acceptance counters, momenta: sample() runs all chains in one launch sequence)
 
     def __init__(self, distribution, initial_state, seed=None, stepsize=1e-1, *, record_stepsize=False, **kwargs):
         if kwargs.get("mode", "exact") not in ("exact", "auto"):

@@ -320,6 +320,13 @@ int gsss_free(void *p_dev, int device);
 int gsss_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device, void *stream);
 int gsss_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream);
 int gsss_memset(void *dst_dev, int value, size_t bytes, int device, void *stream);
+/* The return path of Sampler.sample (mcmc.py:55-77 returns an ndarray; its consumers read it on the host, scripts/curve_vMF.py:119-120)
+ * at PCIe speed: page-locked host memory the device copies into directly (a copy into pageable memory is staged by the driver at
+ * a sixth of the link's rate), and a device-to-host copy that is only ENQUEUED on `stream`, so that the copy of one block of chains
+ * overlaps the kernel of the next (geosss_amd/mcmc.py sample).  The buffer must stay alive until the stream has drained. */
+int gsss_malloc_host(void **out_host, size_t bytes, int device);
+int gsss_free_host(void *p_host);
+int gsss_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream);
 int gsss_stream_synchronize(int device, void *stream);
 
 #ifdef __cplusplus

@@ -223,6 +223,66 @@ def test_sample_api_semantics(gs):
     with pytest.raises(ValueError):
         L.run("nope")
 
+@pytest.mark.parametrize("name,rng,n,kw", [("vmfmix_readme", "philox", 3001, {}), ("vmfmix_readme", "numpy", 1500, {}),
+                                          ("vmfmix_readme", "philox", 4000, {"reject": True, "placement": "packed"}),
+                                          ("bingham_d10_vmax30", "philox", 5000, {"placement": "packed"}),
+                                          ("curve_d10_kappa800", "philox", 2100, {"placement": "packed"}),
+                                          ("bingham_d50_vmax300", "philox", 700, {})])
+def test_sample_in_blocks_equals_one_launch(gs, name, rng, n, kw):
+    """`sample()` -> ndarray runs large ensembles as blocks of chains, the device-to-host copy of one block under the kernel of the
+    next (mcmc.py:55-77's return value at the speed of the link): any number of blocks gives the array, the final states, the
+    counters and the stream position of the one-launch call, bit for bit -- ragged last block, burn-in, thinning and a second
+    call that continues the chains included."""
+    import torch
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    x0 = gs.sample_sphere(d - 1, n, seed=5)
+    kw = dict(kw)
+    cls = gs.RejectionSphericalSliceSampler if kw.pop("reject", False) else gs.ShrinkageSphericalSliceSampler
+    runs = {}
+    for blocks in (1, 2, 7, 16):
+        s = cls(pdf, x0, seed=77, rng=rng, chain_offset=0 if rng == "numpy" else 123, **kw)
+        a = s.sample(23, burnin=9, thin=3, blocks=blocks)
+        b = s.sample(5, blocks=blocks)                               # continues where the first call ended
+        assert a.shape == (n, 23, d) and a.flags["C_CONTIGUOUS"] and a.dtype == np.float64
+        assert s._step == 9 + 22 * 3 + 4
+        runs[blocks] = (a, b, s.state, s.n_reject_per_chain, s.n_tries_per_chain, s._step)
+        t = cls(pdf, x0, seed=77, rng=rng, chain_offset=0 if rng == "numpy" else 123, **kw).sample(23, burnin=9, thin=3, as_tensor=True)
+        assert np.array_equal(t.cpu().numpy(), a)
+    for blocks in (2, 7, 16):
+        for i in range(6):
+            assert np.array_equal(runs[1][i], runs[blocks][i]), (blocks, i)
+    assert np.array_equal(runs[1][1][:, 0], runs[1][0][:, -1])      # row 0 of the second call = last row of the first
+
+
+def test_sample_plans_blocks_for_a_large_array(gs, monkeypatch):
+    """400 000 README chains x 40 rows (384 MB): the default plan pipelines it in several blocks, the array is the one-block
+    array; samplers with further per-chain launch state (RWMH) and running statistics stay in one launch sequence; page-locked
+    blocks go back to the pool when the array is dropped and are reused."""
+    from geosss_amd import _pinned
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    n = 400_000
+    x0 = gs.sample_sphere_device(2, n, seed=3).T
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=5)
+    assert 2 <= s._plan_blocks(0, 40, 1, None) <= 16 and s._plan_blocks(0, 40, 1, 1) == 1
+    assert s._plan_blocks(0, 2, 1, None) == 1                        # 19 MB: one piece
+    a = s.sample(40)
+    b = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=5).sample(40, blocks=1)
+    assert np.array_equal(a, b)
+    addr = a.ctypes.data
+    _pinned.trim()
+    del a
+    c = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=5).sample(40)
+    assert c.ctypes.data == addr and np.array_equal(c, b)           # the dropped array's pages, again
+    m = gs.MetropolisHastings(pdf, x0[:1000], seed=5)
+    assert m._plan_blocks(0, 10**6, 1, None) == 1
+    with pytest.raises(ValueError):
+        m.sample(10, blocks=2)
+    _pinned.trim()
+
+
 
 def test_error_reporting(gs):
     from geosss_amd._lib import GsssError
