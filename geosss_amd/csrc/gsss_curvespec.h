@@ -104,12 +104,12 @@ __host__ __device__ constexpr int curvespec_waves()
     if (NK > 10) return Q <= 2 ? GSSS_CS_WAVES_K17 : GSSS_CS_WAVES_BIG;
     return Q == 1 ? GSSS_CS_WAVES : (Q == 2 ? GSSS_CS_WAVES_Q2 : (Q == 3 ? GSSS_CS_WAVES_Q3 : GSSS_CS_WAVES_BIG));
 }
-template <int L, int Q, int NK, bool HEAVY>
+template <int L, int Q, int NK, bool HEAVY, int R = 0>
 __host__ __device__ constexpr size_t curvespec_lds_doubles()
 {
-    return (size_t)NK * (4 * Q * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
+    return (size_t)NK * (4 * Q * L + R * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
            (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2 +
-           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)4 * Q * kBlock : 0);
+           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)(4 * Q + R) * kBlock : 0);
 }
 
 // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397), FastCurve::level
@@ -171,12 +171,20 @@ __device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &s
     return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
 }
 
-template <int L, int Q, int NK, bool REPLAY, bool STATS = false>
+// R = 1 (round 5): ONE more component per lane behind its Q quads -- the "uneven" layout for dimensions that miss a whole number
+// of quads per lane by a few components: d = 49 .. 52 as <4, 3, +1> (d = 50 is BASELINE cfg4), 97 .. 104 as <8, 3, +1>, 193 .. 208 as
+// <16, 3, +1> (d = 200 likewise).  The fourth quad cost those shapes the third wavefront per SIMD (254 / 246 registers, 15 % of the
+// SIMD cycles idle with nobody to switch to: VERDICT r4); 13 components a lane fit the three-quad register class.  Component
+// 4 Q L + g is lane g's tail slot; rows in LDS are [4 Q L main | L tail] doubles; its normal comes from Philox block 1 + Q L + g / 4
+// (the block of its quad, as in every other kernel: the stream does not know the layout).
+template <int L, int Q, int NK, bool REPLAY, bool STATS = false, int R = 0>
 __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
+    static_assert(R == 0 || (R == 1 && !STATS && Q >= 2), "the tail slot: one component, plain and replay builds");
     using V = CoopVec<L, 4 * Q>;
     using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level
-    constexpr int DPAD = V::DPAD;
+    constexpr int DMAIN = V::DPAD;               // components in the lanes' quads
+    constexpr int DPAD = DMAIN + R * L;          // a knot row in LDS
     constexpr int N = V::N;
     constexpr int kRing = 4 * L;
     constexpr int kScratch = curvespec_scratch_doubles<L, NK>();
@@ -205,7 +213,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             const int r = j / DPAD, w = j - r * DPAD;
             // (round 3: slot PAIRS -- slots 2 p, 2 p + 1 of lane g at words 2 (p L + g), 2 (p L + g) + 1: the same conflict-free
             // broadcast pattern with 16-byte reads, half the LDS instructions)
-            const int c = V::comp((w / 2) % L, 2 * ((w / 2) / L) + (w & 1));
+            const int c = w < DMAIN ? V::comp((w / 2) % L, 2 * ((w / 2) / L) + (w & 1)) : w;  // (tail slots: lane g's at word DMAIN + g)
             lds[j] = (r < k && c < d) ? tb.blob[(size_t)r * d + c] : 0.0;
         }
     } else {
@@ -231,6 +239,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
     // (slots 2 p, 2 p + 1 of thread t at [p][t][2]: 16-byte accesses, conflict-free)
     constexpr bool kParkU = curvespec_parks_u<Q, NK, REPLAY || STATS>();
     double2 *upark = reinterpret_cast<double2 *>(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2) + threadIdx.x;
+    double *upark_t = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2 + (size_t)N * kBlock + threadIdx.x;  // (R: the tail slot's)
     Scalar sc;
     sc.knots = lds;
     sc.seg = sg;
@@ -266,6 +275,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
         const int cc = V::comp(g, i);
         x[i] = (cc < d) ? a.state[(size_t)cc * n + c] : 0.0;
     }
+    const int ct = DMAIN + g;            // (R) the component of this lane's tail slot
+    double xt = (R && ct < d) ? a.state[(size_t)ct * n + c] : 0.0;
 
     PhiloxDraws<V> dr;
     dr.init(a, c, d);
@@ -318,6 +329,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
         c32s.seg32 = reinterpret_cast<const float4 *>(knots + (size_t)NK * DPAD + 4 * (NK - 1));
         // ---------------- draws of the step
         double u[N], u_thr, u_th0;
+        double ut = 0.0;  // (R) the tangent's tail slot
         int pref = 0;  // tries whose uniforms are in the ring: [.., pref)
         if (REPLAY) {
             const bool ok = cursor + d <= a.replay_stride;
@@ -326,6 +338,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 const int cc = V::comp(g, i);
                 u[i] = (cc < d) ? (ok ? rp[cursor + cc] : 0.5) : 0.0;
             }
+            if (R) ut = (ct < d) ? (ok ? rp[cursor + ct] : 0.5) : 0.0;
             if (ok)
                 cursor += d;
             else {
@@ -365,6 +378,20 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 }
             }
             pref = 2 * (L * Q - nq - 1);
+            if (R) {
+                // the tail round: lane g < T draws the block of its tail component's quad (4 Q L + g is word pair (g & 2) of block
+                // 1 + Q L + g / 4: ONE Box-Muller pair, the half of it this lane keeps); lanes past the tail draw block 0 and the
+                // first tries' blocks, as the lanes past the normals do in the even layouts
+                const int T = d - DMAIN;  // 1 .. L tail components (the host picks this build for no other d)
+                const int e = g - T;
+                uint32_t w[4];
+                dr.words(e < 0 ? 1u + (uint32_t)(Q * L + (g >> 2)) : (e == 0 ? 0u : try_base + (uint32_t)(e - 1)), w);
+                double za, zb;
+                box_muller32((g & 2) ? w[2] : w[0], (g & 2) ? w[3] : w[1], tab, za, zb);
+                ut = e < 0 ? ((g & 1) ? zb : za) : 0.0;
+                publish_extra(e, w);
+                pref = 2 * (L - T - 1);
+            }
             if (pref < 0) {  // every lane holds normals: block 0 and the first tries take a round of their own
                 uint32_t w[4];
                 dr.words(g == 0 ? 0u : try_base + (uint32_t)(g - 1), w);
@@ -374,11 +401,19 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             u_thr = u_th0 = 0.0;  // (published to the group's LDS words: read behind the wave_sync that follows the knot dots)
         }
         // ---------------- u = spherical_projection(z, x)   (sphere.py:29-33)
-        const double xx = vdot<V>(x, x);
+        auto gdot = [&](const double (&p)[N], double pt, const double (&r)[N], double rt) -> double {  // (R = 0: vdot<V>, its bits)
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc = fma(p[i], r[i], acc);
+            if (R) acc = fma(pt, rt, acc);
+            return group_sum<L>(acc);
+        };
+        const double xx = gdot(x, xt, x, xt);
         const double rnx = inv_norm(xx);
-        const double cz = vdot<V>(u, x) * rnx;
+        const double cz = gdot(u, ut, x, xt) * rnx;
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
+        if (R) ut = fma(-cz * rnx, xt, ut);
         // ---------------- a_r . u = (a_r . w) / |w|, a_r . x; single-precision pack; the doubles parked for decide()
         const bool refresh = !kRecur || s == 0 || ((step0 + (uint64_t)s) % kCoefRefresh) == 0;
         float q[Curve32<NK, (L < GSSS_CS_PACKED_BELOW)>::kFloats];
@@ -386,6 +421,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             double pw = 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
+            if (R) pw = fma(ut, ut, pw);
             const double rnw = inv_norm(group_sum<L>(pw));
             // Round 4: the knot rows software-pipelined -- row r + 1 is read from LDS while row r is multiplied (N more registers, the
             // same products in the same order, the same bits).  The two-wavefront builds wait on LDS with nobody to switch to (vector
@@ -405,9 +441,11 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 };
                 double2 cur_row[N / 2], nxt_row[N / 2];
                 load_part(0, cur_row, 0, N / 2);
+                double cur_t = R ? knots[DMAIN + g] : 0.0, nxt_t = 0.0;  // (R) the rows' tail slots, one row ahead like the rest
 #pragma unroll
                 for (int r = 0; r < NK; ++r) {
                     if (r + 1 < NK) load_part(r + 1, nxt_row, 0, kAhead);
+                    if (R && r + 1 < NK) nxt_t = knots[(size_t)(r + 1) * DPAD + DMAIN + g];
                     double pu = 0.0, px = 0.0;
 #pragma unroll
                     for (int i = 0; i < N; i += 2) {
@@ -416,6 +454,11 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                         if (refresh) px = fma(kv.x, x[i], px);
                         pu = fma(kv.y, u[i + 1], pu);
                         if (refresh) px = fma(kv.y, x[i + 1], px);
+                    }
+                    if (R) {
+                        pu = fma(cur_t, ut, pu);
+                        if (refresh) px = fma(cur_t, xt, px);
+                        cur_t = nxt_t;
                     }
                     const double au = group_sum<L>(pu) * rnw;
                     const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
@@ -477,6 +520,10 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 u[i] *= rnw;
                 u[i + 1] *= rnw;
                 if (kParkU) upark[(size_t)(i / 2) * kBlock] = make_double2(u[i], u[i + 1]);
+            }
+            if (R) {
+                ut *= rnw;
+                if (kParkU) upark_t[0] = ut;
             }
         }
         wave_sync();  // (one synchronisation for the step's uniforms, the parked coefficients and u)
@@ -623,9 +670,11 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                     x[i] = fma(sn, up.x, cs * x[i]);
                     x[i + 1] = fma(sn, up.y, cs * x[i + 1]);
                 }
+                if (R) xt = fma(sn, upark_t[0], cs * xt);
             } else {
 #pragma unroll
                 for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
+                if (R) xt = fma(sn, ut, cs * xt);
             }
             if (kRecur && g == 0) {
 #pragma unroll
@@ -640,6 +689,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                         const int cc = V::comp(g, i);
                         if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
                     }
+                    if (R && ct < d) a.samples[sample_index(a, row_out, ct, d, c)] = xt;
                 }
                 if constexpr (STATS) stats_update_group<V>(a, c, g, d, x);  // (`alive` is the same in every lane of a group)
                 ++row_out;
@@ -654,6 +704,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             const int cc = V::comp(g, i);
             if (cc < d) a.state[(size_t)cc * n + c] = x[i];
         }
+        if (R && ct < d) a.state[(size_t)ct * n + c] = xt;
         if (g == 0) {
             if (a.n_reject) a.n_reject[c] += n_try - steps_done;
             if (a.n_tries) a.n_tries[c] += n_try;
@@ -664,25 +715,30 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
     if (a.sched != nullptr) SliceSched::publish(a, sched_word);
 }
 
-template <int L, int Q, int NK>
+template <int L, int Q, int NK, int R = 0>
 int do_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, hipStream_t st)
 {
     if (rb.rng_state != nullptr) {
         set_error("in fast mode the numpy stream is served by the one-wavefront-per-chain kernel only; use GSSS_MODE_EXACT");
         return GSSS_E_UNSUPPORTED;
     }
-    if (tb.d > 4 * Q * L || tb.k > NK || tb.k < 2) {
-        set_error("curvespec kernel <%d, %d, %d> cannot hold d=%d, %d knots", L, Q, NK, tb.d, tb.k);
+    if (tb.d > (4 * Q + R) * L || (R && tb.d <= 4 * Q * L) || tb.k > NK || tb.k < 2) {
+        set_error("curvespec kernel <%d, %d, %d, +%d> cannot hold d=%d, %d knots", L, Q, NK, R, tb.d, tb.k);
         return GSSS_E_UNSUPPORTED;
     }
-    const size_t lds = (replay || rb.stats != nullptr ? curvespec_lds_doubles<L, Q, NK, true>() : curvespec_lds_doubles<L, Q, NK, false>()) * sizeof(double);
-    auto kern = replay ? curvespec_kernel<L, Q, NK, true> : curvespec_kernel<L, Q, NK, false>;
+    const size_t lds = (replay || rb.stats != nullptr ? curvespec_lds_doubles<L, Q, NK, true, R>() : curvespec_lds_doubles<L, Q, NK, false, R>()) * sizeof(double);
+    auto kern = replay ? curvespec_kernel<L, Q, NK, true, false, R> : curvespec_kernel<L, Q, NK, false, false, R>;
     if (rb.stats != nullptr) {  // running statistics: a build of its own (the plain kernel carries none of it)
         if (replay) {
             set_error("running statistics are not accumulated from a replayed stream by the group kernels");
             return GSSS_E_UNSUPPORTED;
         }
-        kern = curvespec_kernel<L, Q, NK, false, true>;
+        if constexpr (R == 0) {
+            kern = curvespec_kernel<L, Q, NK, false, true>;
+        } else {
+            set_error("the uneven group layouts carry no statistics build");  // (launch_curvespec never asks)
+            return GSSS_E_UNSUPPORTED;
+        }
     }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

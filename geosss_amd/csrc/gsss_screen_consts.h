@@ -17,8 +17,10 @@ constexpr float kSinCosErr32 = 3.5e-7f;
 constexpr float kUnit32 = 5.9604645e-8f;  // 2^-24
 constexpr float kExp2Err32 = 8.5e-8f;     // relative error of v_exp_f32 on normal results (exhaustive sweep)
 // log2 of a double via frexp + v_log_f32 of the mantissa m in [0.5, 1) rounded to single: the hardware's error at the rounded
-// mantissa + half an ulp of it over m ln 2
-constexpr float kLog2Err32 = 1.3e-7f;
+// mantissa (5.95e-8) + half an ulp of it over m ln 2 (8.6e-8 at m = 0.5); the exhaustive sweep of the SUM gives 1.4267e-7.
+// (Rounds 2-4 had 1.3e-7 here -- the two maxima taken apart and the second misjudged; the 25 % the margins carry on top covered
+// it, the first run of the sweep as a test found it.)
+constexpr float kLog2Err32 = 1.45e-7f;
 // relative error of v_sqrt_f32 on normal arguments (the curve screen's |P y|; inside the "40 x 2^-24 of arithmetic" of
 // Curve32::eval_error, which allows 2^-22 for it)
 constexpr float kSqrtRelErr32 = 2.3841858e-7f;  // 2^-22

@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(kSweepBlock) f32_sweep_kernel(uint32_t lo_bits
         if (which == 0) {
             // sincos_rev32 (gsss_screen.h): t = fl32(theta / 2 pi), |t| <= 1.  [0], [1]: the hardware at the float; [2], [3]: against
             // ANY theta whose revolutions round to this float (|d/dt sin 2 pi t| <= 2 pi)
-            const double a = two_pi * (double)x, slack = two_pi * half_ulp(x);
+            // (|t| = 1 ends the range: only revolutions BELOW it round to it, from within 2^-25)
+            const double a = two_pi * (double)x, slack = two_pi * (fabsf(x) == 1.0f ? 2.9802322387695312e-8 : half_ulp(x));
             const double es = fabs((double)__builtin_amdgcn_sinf(x) - sin(a)), ec = fabs((double)__builtin_amdgcn_cosf(x) - cos(a));
             e[0] = fmax(e[0], es);
             e[1] = fmax(e[1], ec);

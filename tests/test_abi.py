@@ -204,17 +204,20 @@ def test_group_kernels_do_not_spill():
     own resource remarks, device code only (hipcc cross-compiles here)."""
     from geosss_amd import build
     ru = build.resource_usage("gsss_fast_curvespec.hip")
-    want = {"ILi4ELi1ELi10ELb0ELb0E": 3, "ILi16ELi1ELi10ELb0ELb0E": 3, "ILi4ELi2ELi10ELb0ELb0E": 3, "ILi4ELi3ELi10ELb0ELb0E": 3,
-            "ILi8ELi3ELi10ELb0ELb0E": 3, "ILi16ELi3ELi10ELb0ELb0E": 3,
-            "ILi4ELi1ELi17ELb0ELb0E": 3, "ILi4ELi2ELi17ELb0ELb0E": 3, "ILi16ELi1ELi17ELb0ELb0E": 3, "ILi16ELi2ELi17ELb0ELb0E": 3,
-            "ILi4ELi4ELi10ELb0ELb0E": 2, "ILi8ELi4ELi10ELb0ELb0E": 2, "ILi16ELi4ELi10ELb0ELb0E": 2}  # <L, Q, NK, replay, stats> -> waves per SIMD
+    want = {"ILi4ELi1ELi10ELb0ELb0ELi0E": 3, "ILi16ELi1ELi10ELb0ELb0ELi0E": 3, "ILi4ELi2ELi10ELb0ELb0ELi0E": 3, "ILi4ELi3ELi10ELb0ELb0ELi0E": 3,
+            "ILi8ELi3ELi10ELb0ELb0ELi0E": 3, "ILi16ELi3ELi10ELb0ELb0ELi0E": 3,
+            "ILi4ELi1ELi17ELb0ELb0ELi0E": 3, "ILi4ELi2ELi17ELb0ELb0ELi0E": 3, "ILi16ELi1ELi17ELb0ELb0ELi0E": 3, "ILi16ELi2ELi17ELb0ELb0ELi0E": 3,
+            "ILi4ELi4ELi10ELb0ELb0ELi0E": 2, "ILi8ELi4ELi10ELb0ELb0ELi0E": 2, "ILi16ELi4ELi10ELb0ELb0ELi0E": 2,
+            # round 5: three quads + one tail component per lane (d = 49 .. 52, 97 .. 104, 193 .. 208; cfg4's d = 50 / 200)
+            "ILi4ELi3ELi10ELb0ELb0ELi1E": 3, "ILi8ELi3ELi10ELb0ELb0ELi1E": 3, "ILi16ELi3ELi10ELb0ELb0ELi1E": 3}  # <L, Q, NK, replay, stats, tail> -> waves per SIMD
     # scratch a build may hold (bytes a lane).  Two and three component quads per lane are the MEASURED exceptions to "no
     # scratch": three wavefronts with 128 .. 224 bytes spilled are 16-22 % faster than two without (gsss_curvespec.h,
     # profiles/r04_ab_q2_three_waves.log; the resident wavefronts' scratch stays in or near the L2), which four quads are not
     # (d = 50: 320 bytes, 15 % slower): those hold nothing in scratch
-    budget = {"ILi4ELi1ELi10ELb0ELb0E": 12, "ILi16ELi1ELi10ELb0ELb0E": 12, "ILi4ELi2ELi10ELb0ELb0E": 128, "ILi4ELi3ELi10ELb0ELb0E": 224,
-              "ILi8ELi3ELi10ELb0ELb0E": 148, "ILi16ELi3ELi10ELb0ELb0E": 200,
-              "ILi4ELi1ELi17ELb0ELb0E": 168, "ILi4ELi2ELi17ELb0ELb0E": 204, "ILi16ELi1ELi17ELb0ELb0E": 164, "ILi16ELi2ELi17ELb0ELb0E": 208}
+    budget = {"ILi4ELi1ELi10ELb0ELb0ELi0E": 12, "ILi16ELi1ELi10ELb0ELb0ELi0E": 12, "ILi4ELi2ELi10ELb0ELb0ELi0E": 128, "ILi4ELi3ELi10ELb0ELb0ELi0E": 224,
+              "ILi8ELi3ELi10ELb0ELb0ELi0E": 148, "ILi16ELi3ELi10ELb0ELb0ELi0E": 200,
+              "ILi4ELi1ELi17ELb0ELb0ELi0E": 168, "ILi4ELi2ELi17ELb0ELb0ELi0E": 204, "ILi16ELi1ELi17ELb0ELb0ELi0E": 164, "ILi16ELi2ELi17ELb0ELb0ELi0E": 208,
+              "ILi4ELi3ELi10ELb0ELb0ELi1E": 236, "ILi8ELi3ELi10ELb0ELb0ELi1E": 204, "ILi16ELi3ELi10ELb0ELb0ELi1E": 264}
     seen = 0
     for name, r in ru.items():
         for key, waves in want.items():

@@ -3,7 +3,7 @@
 The small same-stream parity tests (test_hip_parity.py) run a few thousand chains for ~100 steps: one resident round of
 workgroups, no slicing.  The bench's launches are different animals -- 10^6 chains x 1000 steps of the README mixture run
 1.5 rounds of five-workgroups-per-CU `screened_kernel<3, ScreenVmf<3,3>>`, two chains per lane, the last 674 chunks cut into
-128-step slices that hand their state over through HBM; 10^5 chains of the d = 50 curve run `curvespec_kernel<4,4,10>` with
+128-step slices that hand their state over through HBM; 10^5 chains of the d = 50 curve run `curvespec_kernel<4,3,10,+1>` with
 EVERY chunk sliced.  Chains are keyed by their global id, so the oracle can check any subset of such a launch in seconds:
 blocks of chain ids from the unsliced rounds, from the sliced tail, across the boundary between them and from the ragged
 last chunk are compared with `oracle.run(..., chain_offset=...)` -- kept rows and final states at 1e-10, tries exactly.
@@ -123,12 +123,12 @@ def test_curve_d50_launch_matches_oracle(gs, oracle, monkeypatch):
     def blocks(first, n_chunks):
         return [("first chunks", 0, 160), ("middle", (n_chunks // 2) * per - 30, 160), ("ragged last chunk and its neighbours", 100_000 - 160, 160)]
 
-    n_checked, where, frac, _ = _check_blocks(gs, oracle, "curve_d50", 100_000, blocks, "curvespec_kernel<4, 4, 10", per, (1.0, 1.0), monkeypatch, per_cu=2)
+    n_checked, where, frac, _ = _check_blocks(gs, oracle, "curve_d50", 100_000, blocks, "curvespec_kernel<4, 3, 10, +1>", per, (1.0, 1.0), monkeypatch, per_cu=3)
     assert n_checked == 480
 
 
 @pytest.mark.parametrize("workload,kernel,per,m,per_cu", [("curve_d10", "curvespec_kernel<4, 1, 10", 64, 320, 3), ("curve_d24", "curvespec_kernel<4, 2, 10", 64, 200, 3),
-                                                           ("curve_d200", "curvespec_kernel<16, 4, 10", 16, 48, 2)])
+                                                           ("curve_d200", "curvespec_kernel<16, 3, 10, +1>", 16, 48, 3)])
 def test_curve_launches_match_oracle(gs, oracle, monkeypatch, workload, kernel, per, m, per_cu):
     """cfg4's other points at their full size (10^5 chains x 1000 transitions, every chunk sliced): three- and two-wavefront builds,
     four- and sixteen-lane groups, the packed segment evaluation with the full-curve copy of its loop."""
