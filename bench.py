@@ -511,6 +511,7 @@ def time_sharded_config(gs, torch, dist, name, n, S, rank, world, barrier, gathe
     chain ids rank * 10^6 ..., final states gathered: SURVEY.md section 8(d)/(e); the reference's fan-out of independent
     processes, scripts/mixture_vMF.py:137-149).  Same bracketing as the headline: barrier + synchronize on both sides, the gather
     inside the timed region, max over ranks."""
+    n = int(os.environ.get("GSSS_BENCH_SHARDED_CHAINS", n))          # (tests rehearse the path with a smaller ensemble)
     pdf, d = make_target(gs, name)
     x0 = gs.sample_sphere_device(d - 1, n, seed=0, chain_offset=rank * n)
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=seed, chain_offset=rank * n)
@@ -546,7 +547,11 @@ def time_sharded_config(gs, torch, dist, name, n, S, rank, world, barrier, gathe
     assert final.shape[1] == n * world
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     total = n * S * reps * world
-    return {"name": name + "_sharded", "workload": f"{name}: {n} chains per GPU x {S} transitions per launch, thin={thin}, chain ids "
+    digest = None
+    if os.environ.get("GSSS_BENCH_CHECKSUM"):  # (tests: the gathered [d, world * n] states, to be compared with a one-process run)
+        import hashlib
+        digest = hashlib.sha256(final.contiguous().cpu().numpy().tobytes()).hexdigest()
+    return {"name": name + "_sharded", "final_sha256": digest, "chains_per_gpu": n, "workload": f"{name}: {n} chains per GPU x {S} transitions per launch, thin={thin}, chain ids "
                                                    f"rank * {n} ..., final states gathered, {world} ranks",
             "value": total / float(tmax.item()), "unit": "chain-steps/s", "launches": reps, "kernel": kernel, "kernel_ms": kern_ms,
             "gather_ms": float(g0.elapsed_time(g1)), "ranks_seen": int(ones.item()), "tries_per_step": int(agg[0].item()) / total,

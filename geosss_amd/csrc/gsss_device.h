@@ -121,7 +121,9 @@ struct SliceSched {
                 // that a lost predecessor ends in error flags instead of a hung GPU; it is not a scheduling decision.
                 uint32_t ok = 1;
                 uint64_t spins = 0;
-                const uint64_t limit = (uint64_t)(slice + 1u) << 22;
+                // (capped at ~30 s: the legitimate wait is at most kMaxSlices slice times of milliseconds, and a slice that gave up
+                // publishes its progress like any other, so its successors do not wait out limits of their own: ADVICE r4)
+                const uint64_t limit = (uint64_t)(slice + 1u < 8u ? slice + 1u : 8u) << 22;
                 while (__hip_atomic_load(progress(a) + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < slice) {
                     __builtin_amdgcn_s_sleep(32);
                     if (++spins > limit) {

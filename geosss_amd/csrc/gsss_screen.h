@@ -34,6 +34,9 @@
 #ifndef GSSS_VMF_ONE_ALL
 #define GSSS_VMF_ONE_ALL 0  // (measurement: build it for every bucket; GSSS_ONE_PER_LANE=2 then runs it)
 #endif
+#ifndef GSSS_S2_TRY32
+#define GSSS_S2_TRY32 0  // (experiment, round 5: on S^2 a try's uniform is ONE 32-bit word of the stream, four tries per Philox block)
+#endif
 #ifndef GSSS_SCREEN_REGEN_THR
 #define GSSS_SCREEN_REGEN_THR 1  // (A/B: 0 parks the threshold uniform of the S^2 mixtures as round 2 did)
 #endif
@@ -957,7 +960,10 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
     };
 
     // up to two proposals, screened in single precision (one Philox block feeds a pair of tries: the first
-    // uniform of block j is try 2j, the second try 2j + 1)
+    // uniform of block j is try 2j, the second try 2j + 1) -- on S^2 (stream philox-v3) up to FOUR: a try's uniform is one 32-bit
+    // word, block j feeds tries 4j .. 4j + 3
+    constexpr bool kTry32 = D == 3 && !REPLAY && GSSS_S2_TRY32;
+    constexpr int kPerAttempt = kTry32 ? 4 : 2;
     auto attempt = [&]() {
         if (cur.t >= max_tries) {
             count_tries();
@@ -966,14 +972,24 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
             return;
         }
         double u_pair[2];
-        if (!REPLAY) philox().block(kTryBase + (uint32_t)(cur.t >> 1), u_pair[0], u_pair[1]);
-        const int first = REPLAY ? 0 : (cur.t & 1);  // odd: the pair's first try was decided in double precision already
+        uint32_t w_try[4];
+        if constexpr (kTry32) {
+            philox().words(kTryBase + (uint32_t)(cur.t >> 2), w_try);
+        } else if (!REPLAY) {
+            philox().block(kTryBase + (uint32_t)(cur.t >> 1), u_pair[0], u_pair[1]);
+        }
+        // (odd / mid-block: the tries before this one were made already -- the last of them decided in double precision)
+        const int first = REPLAY ? 0 : (cur.t & (kPerAttempt - 1));
         bool stopped = false;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kPerAttempt; ++h) {
             if (!stopped && h >= first && (h == first || cur.t < max_tries) &&
                 !(REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
-                const double uu = REPLAY ? replay_take() : u_pair[h];
+                double uu;
+                if constexpr (kTry32)
+                    uu = (double)w_try[h] * 0x1.0p-32;
+                else
+                    uu = REPLAY ? replay_take() : u_pair[h & 1];
                 if (REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED)) {
                     stopped = true;  // nothing left to propose with
                 } else {
@@ -1339,13 +1355,25 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
                 if (kStageP > 1 && rb.samples != nullptr && rb.keep_rows > 0 && !(env_stage && env_stage[0] == '0')) {
                     const size_t lds_staged = lds + (size_t)(kStageP - 1) * D * kBlock * sizeof(double);
                     if (resident_workgroups(reinterpret_cast<const void *>(kern_one), lds_staged) >= resident_workgroups(reinterpret_cast<const void *>(kern_one), lds)) {
-                        if (lds_staged > 48 * 1024)
-                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern_one), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged);
-                        stage_rows = true;
-                        lds = lds_staged;
+                        // (the attribute first: rows are held back only if the launch can have the LDS for them)
+                        const bool can = lds_staged <= 48 * 1024 ||
+                                         hipFuncSetAttribute(reinterpret_cast<const void *>(kern_one), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged) == hipSuccess;
+                        if (can) {
+                            stage_rows = true;
+                            lds = lds_staged;
+                        } else {
+                            (void)hipGetLastError();
+                        }
                     }
                 }
             }
+        }
+    }
+    if (lds > 48 * 1024) {  // the kernel that IS launched, with the LDS it is launched with (the one-chain-per-lane build got none)
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu B of LDS) failed: %s", lds, hipGetErrorString(ea));
+            return GSSS_E_HIP;
         }
     }
     const int64_t n_chunks = (rb.n_chains + per_block - 1) / per_block;

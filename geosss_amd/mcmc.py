@@ -64,6 +64,19 @@ def determine_burnin(n_samples, burnin):
 _children_built = {}  # id(bit generator) -> [the bit generator, samplers keyed from it so far]
 
 
+def _forget_dead_generators():
+    """Drop the bit generators nobody but this table holds any more (numpy's bit generators take no weak references, so the
+    table holds strong ones and looks at the reference count: the entry's list, the loop variable and getrefcount's argument).
+    A generator that is still alive keeps its entry -- evicting it would restart its count and hand the next sampler built from
+    it the key of the first."""
+    import sys
+    for key in list(_children_built):
+        bg = _children_built[key][0]
+        if sys.getrefcount(bg) <= 3:
+            del _children_built[key]
+        del bg
+
+
 def seed_to_key(seed):
     """64-bit Philox key from what np.random.default_rng accepts as `seed` (mcmc.py:45).  A Generator / BitGenerator is
     neither advanced nor otherwise changed: successive samplers built from one generator get successive children of its
@@ -93,8 +106,8 @@ def seed_to_key(seed):
             # the same seed starts at 0 again: same program, same keys)
             entry = _children_built.get(id(bg))
             if entry is None or entry[0] is not bg:
-                if len(_children_built) >= 1024:               # (bounded: forget the generator seen longest ago)
-                    _children_built.pop(next(iter(_children_built)))
+                if len(_children_built) >= 1024:
+                    _forget_dead_generators()                  # (bounded by the LIVE generators: a live one's count never restarts)
                 entry = _children_built[id(bg)] = [bg, 0]      # (the reference keeps the id from being reused)
             count = entry[1]
             entry[1] = count + 1

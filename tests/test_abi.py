@@ -147,6 +147,16 @@ def test_seed_argument_handling():
     h = np.random.default_rng(5)
     assert (seed_to_key(h), seed_to_key(h)) == (k1, k2)                  # reproducible: same generator history, same keys
     assert seed_to_key(h.bit_generator) not in (k1, k2)                  # a BitGenerator spawns from the same sequence
+    # the count of a LIVE generator never restarts, however many other generators pass by (the table used to evict
+    # the generator seen longest ago at 1024 entries, alive or not, and hand its next sampler the key of its first)
+    from geosss_amd import mcmc
+    live = [np.random.default_rng(100 + i) for i in range(700)]
+    for x in live:
+        seed_to_key(x)
+    for i in range(1500):
+        seed_to_key(np.random.default_rng(10_000 + i))                   # dropped at once: forgotten when the table fills
+    assert seed_to_key(g) not in (k1, k2)
+    assert all(mcmc._children_built[id(x.bit_generator)][1] == 1 for x in live) and len(mcmc._children_built) < 1800
     pdf = gs.MixtureModel([gs.VonMisesFisher([0.0, 0.0, 5.0])])
     with pytest.raises(ValueError):
         gs.ShrinkageSphericalSliceSampler(pdf, np.eye(3), [1, 2, 3])

@@ -111,3 +111,36 @@ def test_two_ranks_end_to_end_on_one_gpu():
     o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert o1["n_gpus"] == 1 and o1["rccl"]["ranks_seen"] == 1
     assert set(o1) - {"configs"} <= set(out) | {"configs"}
+
+
+@pytest.mark.gpu
+def test_four_ranks_time_cfg5_sharded_and_gather_what_one_process_computes():
+    """`bench.py --gpus N` times cfg5's own workload on every rank (vMF mixture K = 10 kappa = 500, chain ids rank * n ..., final
+    states gathered; BASELINE.json configs[4], the reference's fan-out scripts/mixture_vMF.py:137-149).  Rehearsed with four gloo
+    ranks as separate processes on the one GPU: every rank is seen, and the gathered [d, 4 n] states are, bit for bit, what ONE
+    process computes for chains 0 .. 4 n - 1 with the same sequence of launches."""
+    import hashlib
+    import torch
+    import bench
+    import geosss_amd as gs
+    n, S = 60_000, 200
+    r = _run(["--gpus", "4", "--steps", "1", "--warmup", "1", "--chains", "20000", "--inner", str(S), "--no-cpu-baseline", "--no-ess"],
+             {"GSSS_BENCH_BACKEND": "gloo", "GSSS_BENCH_SHARDED_CHAINS": str(n), "GSSS_BENCH_CHECKSUM": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = r.stdout.strip().splitlines()[-1]                          # the LAST stdout line is the JSON line
+    out = json.loads(line)
+    assert len(line) < 6000 and out["n_gpus"] == 4 and out["rccl"]["ranks_seen"] == 4
+    sh = [c for c in out["configs"] if c["name"] == "vmfmix_k10_kappa500_sharded"][0]
+    assert sh["ranks_seen"] == 4 and sh["gather_ms"] > 0 and sh["value"] > 0
+    full = json.load(open(os.path.join(ROOT, out["full_record"])))
+    rec = [c for c in full["configs"] if c["name"] == "vmfmix_k10_kappa500_sharded"][0]
+    assert rec["chains_per_gpu"] == n and rec["chains_in_error"] == 0 and 6.0 < rec["tries_per_step"] < 7.2
+    # one process, chains 0 .. 4 n - 1, the launches of time_sharded_config: 100 warm-up transitions, then `launches` x S kept every 100th
+    pdf, d = bench.make_target(gs, "vmfmix_k10_kappa500")
+    x0 = gs.sample_sphere_device(d - 1, 4 * n, seed=0)
+    s = gs.ShrinkageSphericalSliceSampler(pdf, x0.T, seed=3521)
+    s.advance(100)
+    for _ in range(rec["launches"]):
+        s.advance(S, thin=100)
+    torch.cuda.synchronize()
+    assert hashlib.sha256(s.state_device.contiguous().cpu().numpy().tobytes()).hexdigest() == rec["final_sha256"]

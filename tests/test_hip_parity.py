@@ -279,7 +279,7 @@ def test_sample_plans_blocks_for_a_large_array(gs, monkeypatch):
     m = gs.MetropolisHastings(pdf, x0[:1000], seed=5)
     assert m._plan_blocks(0, 10**6, 1, None) == 1
     with pytest.raises(ValueError):
-        m.sample(10, blocks=2)
+        m._plan_blocks(0, 10, 1, 2)
     _pinned.trim()
 
 

@@ -14,5 +14,6 @@ print("$W tail=$T", j["config"]["kernel"], "kernel_ms", j["kernel_ms"], "value %
 PY
   done
 done
+tools/ab_libs.sh "libgsss_hip.so libgsss_try32.so libgsss_hip.so libgsss_try32.so" "vmfmix_readme:1000000 vmfmix_k10_kappa500:1000000" > gpurun_out/r5_ab_try32.log 2>&1; cat gpurun_out/r5_ab_try32.log
 python tools/bench_host_api.py --json gpurun_out/r5_host_api.json > gpurun_out/r5_host_api.log 2>&1 || { tail -20 gpurun_out/r5_host_api.log; exit 1; }
 cat gpurun_out/r5_host_api.log
