@@ -118,10 +118,11 @@ STREAM_NUMPY = ("numpy PCG64 + ziggurat, one generator per chain (SeedSequence(s
 
 # What the library's counter-based stream draws per step: said in the bench line so that nobody reads
 # "Philox" as "the reference's arithmetic on another generator"
-STREAM_S2 = ("philox-v2: Philox4x32-10 keyed by (seed, chain, step); S^2: the unit tangent drawn as ONE angle (32 bit) instead of "
-             "three projected normals, theta0 32 bit, threshold and try uniforms 53 bit")
-STREAM_D = ("philox-v2: Philox4x32-10 keyed by (seed, chain, step); d normals per step by single-precision Box-Muller from 32-bit "
-            "words (they only set the tangent's direction), threshold / theta0 / try uniforms 53 bit")
+STREAM_S2 = ("philox-v3: Philox4x32-10 keyed by (seed, chain, step); S^2: the unit tangent drawn as ONE angle (32 bit) instead of "
+             "three projected normals, theta0 32 bit, threshold uniform 53 bit, a try's uniform ONE 32-bit word (four tries a block)")
+STREAM_D = ("philox-v3: Philox4x32-10 keyed by (seed, chain, step); d normals per step by single-precision Box-Muller from 32-bit "
+            "words (they only set the tangent's direction), threshold / theta0 uniforms 53 bit, a try's uniform ONE 32-bit word "
+            "(four tries a block)")
 
 
 def stream_description(d):
@@ -806,8 +807,8 @@ def main(argv=None):
                                    "launch, thin=%d" % thin,
                        "stream": STREAM_NUMPY if args.rng == "numpy" else stream_description(d),
                        "stream_short": "numpy PCG64+ziggurat per chain (mcmc.py:387-395 order)" if args.rng == "numpy" else (
-                           "philox-v2 (chain,step)-keyed; S2: tangent = one 32-bit angle" if d == 3 else
-                           "philox-v2 (chain,step)-keyed; f32 Box-Muller normals, 53-bit uniforms"),
+                           "philox-v3 (chain,step)-keyed; S2: tangent = one angle; 32-bit tries" if d == 3 else
+                           "philox-v3 (chain,step)-keyed; f32 Box-Muller normals; 32-bit tries"),
                        "target": wl_key, "d": d, "chains_per_gpu": n, "transitions_per_step": S, "thin": thin,
                        "slice_steps": slice_steps, "sliced_fraction": round(sliced_frac, 4),
                        "kept_rows_layout": layout,

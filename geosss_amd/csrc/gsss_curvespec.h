@@ -85,7 +85,7 @@ namespace gsss {
 template <int L, int NK>
 __host__ __device__ constexpr int curvespec_scratch_doubles()
 {
-    return 2 + 4 * L + 2 * NK;  // U_threshold, U_theta0 | a ring of 4 L try uniforms | the step's double-precision coefficients
+    return 2 + 4 * L + 2 * NK;  // U_threshold, U_theta0 | a ring of 8 L try words (4 L doubles of a replayed stream) | the step's double-precision coefficients
 }
 // The tangent u rests in LDS while the tries run where the registers would not hold it beside the try loop's: the 17-knot
 // builds with more than four components per lane.  (Round 3: the 10-knot builds kept parking it at two wavefronts per SIMD, where
@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
     constexpr int DMAIN = V::DPAD;               // components in the lanes' quads
     constexpr int DPAD = DMAIN + R * L;          // a knot row in LDS
     constexpr int N = V::N;
-    constexpr int kRing = 4 * L;
+    constexpr int kRing = 4 * L;      // doubles
+    constexpr int kRing32 = 8 * L;    // the same words as 32-bit try words (philox-v3: a try's uniform is one word of the stream)
     constexpr int kScratch = curvespec_scratch_doubles<L, NK>();
     // a_i.x by recurrence between refreshes (every kCoefRefresh global steps and at the first step of a launch or slice) for
     // sixteen-lane groups; L = 4 / 8 form it from x at every step, so that a run split over launches gives the same bits.
@@ -233,6 +234,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
     c32.stage(reinterpret_cast<float4 *>(sg + 4 * (NK - 1)), sg, k - 1, tb.kappa);
     double *scr = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (threadIdx.x / L);
     double *ring = scr + 2;
+    uint32_t *ring32 = reinterpret_cast<uint32_t *>(ring);
     double *coef = ring + kRing;  // [NK][2]: a_i.x, a_i.u of the step (for the double-precision decisions), 16-byte aligned
     const fm::Tables tab = stage_tables(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L));
     // Q >= 2 (d > 64): u is only needed again when the chain moves; its 8 Q registers are lent to the try loop meanwhile
@@ -302,16 +304,15 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // one Philox round of "extra" blocks: extra index e = 0 is block 0, e >= 1 the tries' block e - 1
+    // one Philox round of "extra" blocks: extra index e = 0 is block 0, e >= 1 the tries' block e - 1 -- the words of tries
+    // 4 (e - 1) .. 4 (e - 1) + 3 (philox-v3), stored as they are (one 16-byte store; a round of L blocks is 4 L tries: with the L a batch
+    // may still hold, 5 L of the ring's 8 L words)
     auto publish_extra = [&](int e, const uint32_t (&w)[4]) {
-        const double p0 = u53(w[0], w[1]), p1 = u53(w[2], w[3]);
         if (e == 0) {
-            scr[0] = p0;
-            scr[1] = p1;
+            scr[0] = u53(w[0], w[1]);
+            scr[1] = u53(w[2], w[3]);
         } else if (e > 0) {
-            const int t0 = 2 * (e - 1);
-            ring[t0 & (kRing - 1)] = p0;
-            ring[(t0 + 1) & (kRing - 1)] = p1;
+            *reinterpret_cast<uint4 *>(ring32 + ((4 * (e - 1)) & (kRing32 - 1))) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
 
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            pref = 2 * (L * Q - nq - 1);
+            pref = 4 * (L * Q - nq - 1);
             if (R) {
                 // the tail round: lane g < T draws the block of its tail component's quad (4 Q L + g is word pair (g & 2) of block
                 // 1 + Q L + g / 4: ONE Box-Muller pair, the half of it this lane keeps); lanes past the tail draw block 0 and the
@@ -390,13 +391,13 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 box_muller32((g & 2) ? w[2] : w[0], (g & 2) ? w[3] : w[1], tab, za, zb);
                 ut = e < 0 ? ((g & 1) ? zb : za) : 0.0;
                 publish_extra(e, w);
-                pref = 2 * (L - T - 1);
+                pref = 4 * (L - T - 1);
             }
             if (pref < 0) {  // every lane holds normals: block 0 and the first tries take a round of their own
                 uint32_t w[4];
                 dr.words(g == 0 ? 0u : try_base + (uint32_t)(g - 1), w);
                 publish_extra(g, w);
-                pref = 2 * (L - 1);
+                pref = 4 * (L - 1);
             }
             u_thr = u_th0 = 0.0;  // (published to the group's LDS words: read behind the wave_sync that follows the knot dots)
         }
@@ -582,9 +583,9 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             } else {
                 while (t_base + L > pref) {  // (wave-uniform) another round: lane g draws the tries' block pref / 2 + g
                     uint32_t w[4];
-                    dr.words(try_base + (uint32_t)(pref >> 1) + (uint32_t)g, w);
-                    publish_extra(1 + (pref >> 1) + g, w);
-                    pref += 2 * L;
+                    dr.words(try_base + (uint32_t)(pref >> 2) + (uint32_t)g, w);
+                    publish_extra(1 + (pref >> 2) + g, w);
+                    pref += 4 * L;
                     wave_sync();
                 }
             }
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             if (shrink) {  // (two loops: the sampler is the same for the whole launch, a select per end and try otherwise)
 #pragma unroll
                 for (int qq = 0; qq < L; ++qq) {
-                    const double ut = REPLAY ? ring[qq] : ring[(t_base + qq) & (kRing - 1)];
+                    const double ut = REPLAY ? ring[qq] : try_uniform(ring32[(t_base + qq) & (kRing32 - 1)]);
                     const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
                     if (g == qq) my_theta = theta;
                     const bool neg = theta < 0.0;               // mcmc.py:400, assuming try qq is rejected
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             } else {
 #pragma unroll
                 for (int qq = 0; qq < L; ++qq) {
-                    const double ut = REPLAY ? ring[qq] : ring[(t_base + qq) & (kRing - 1)];
+                    const double ut = REPLAY ? ring[qq] : try_uniform(ring32[(t_base + qq) & (kRing32 - 1)]);
                     const double theta = fma(hi - lo, ut, lo);  // mcmc.py:367, 395: the bracket stays (0, 2 pi)
                     if (g == qq) my_theta = theta;
                 }

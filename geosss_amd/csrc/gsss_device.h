@@ -392,6 +392,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
+// The uniform of a try from ONE word of the stream (philox-v3): theta = lo + (hi - lo) w / 2^32 has 32 bits of resolution relative
+// to the bracket, however far it has shrunk.  Exact: a 32-bit integer and a power of two.
+__device__ __forceinline__ double try_uniform(uint32_t w) { return (double)w * 0x1.0p-32; }
+
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 {
     // ((a >> 5) 2^26 + (b >> 6)) / 2^53 as numpy forms it, without the 64-bit integer detour: both halves convert exactly,
@@ -647,7 +651,7 @@ struct PhiloxDraws {
     __device__ __forceinline__ void finish(const RunBlock &, int64_t, bool) const {}
     uint32_t k0, k1, c1, c2, c3, chain_hi;
     int d, t;
-    double cached;
+    uint32_t cw0, cw1, cw2, cw3;  // the words of the try block in use (next_try)
     bool exhausted;
 
     __device__ __forceinline__ void init(const RunBlock &a, int64_t chain_local, int d_)
@@ -734,13 +738,20 @@ struct PhiloxDraws {
     {
         block(0u, u_thr, u_theta0);
     }
+    // the uniform of try t (mcmc.py:395): ONE 32-bit word -- word t % 4 of block 1 + nb + t / 4 (philox-v3, round 5; try_uniform)
     __device__ __forceinline__ double next_try()
     {
         const int tt = t++;
-        if (tt & 1) return cached;
-        double u0;
-        block(1u + (uint32_t)((d + 3) >> 2) + (uint32_t)(tt >> 1), u0, cached);
-        return u0;
+        if ((tt & 3) == 0) {
+            uint32_t w[4];
+            words(1u + (uint32_t)((d + 3) >> 2) + (uint32_t)(tt >> 2), w);
+            cw0 = w[0];
+            cw1 = w[1];
+            cw2 = w[2];
+            cw3 = w[3];
+        }
+        const int h = tt & 3;
+        return try_uniform(h == 0 ? cw0 : (h == 1 ? cw1 : (h == 2 ? cw2 : cw3)));
     }
     // RWMH (mcmc.py:143): r = sqrt(2 gamma(d/2)) is a chi_d variate -- here the norm of d further normals
     __device__ __forceinline__ double chi(int g) const

@@ -569,7 +569,12 @@ __global__ void __launch_bounds__(kBlock) fast_kernel(TargetBlock tb, RunBlock a
             return;
         }
         double u_pair[2];
-        if (!REPLAY) philox().block(kTryBase + (uint32_t)(cur.t >> 1), u_pair[0], u_pair[1]);
+        if (!REPLAY) {  // philox-v3: a try's uniform is one 32-bit word, block j feeds tries 4j .. 4j + 3; this attempt makes tries t, t + 1 (t even)
+            uint32_t w[4];
+            philox().words(kTryBase + (uint32_t)(cur.t >> 2), w);
+            u_pair[0] = try_uniform((cur.t & 2) ? w[2] : w[0]);
+            u_pair[1] = try_uniform((cur.t & 2) ? w[3] : w[1]);
+        }
         bool accepted = false;
         double sn = 0.0, cs = 1.0, lvl = 0.0;
 #pragma unroll
@@ -1221,12 +1226,14 @@ __global__ void __launch_bounds__(kBlock, V::N >= 16 ? 2 : 4) coopfast_kernel(Ta
                 err |= GSSS_CHAIN_MAX_TRIES;
                 break;
             }
-            double up[2];
-            if (!REPLAY) dr.block(try_base + (uint32_t)(t >> 1), up[0], up[1]);
+            // philox-v3: a try's uniform is one 32-bit word; block j feeds tries 4j .. 4j + 3 (a replayed stream hands over doubles)
+            constexpr int kPerBlock = REPLAY ? 2 : 4;
+            uint32_t wt[4] = {0u, 0u, 0u, 0u};
+            if (!REPLAY) dr.words(try_base + (uint32_t)(t >> 2), wt);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < kPerBlock; ++h) {
                 if (!accepted && (h == 0 || t < a.max_tries) && !(REPLAY && (err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
-                    const double uu = REPLAY ? take() : up[h];
+                    const double uu = REPLAY ? take() : try_uniform(wt[h]);
                     const double theta = fma(hi - lo, uu, lo);
                     ++t;
                     fm::sincos_small(theta, sn, cs);
@@ -1403,6 +1410,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
 
     for (int64_t s = 0; s < a.n_steps; ++s) {
         double u[D], u_thr, u_th0, pair_u0 = 0.0, pair_u1 = 0.0;
+        uint32_t try_w[4] = {0u, 0u, 0u, 0u};  // Philox: the words of this lane's block (lanes 0-7: the first tries' blocks)
         uint32_t tangent_word = 0u;  // d = 3, Philox: word 3 of the step's block 0 (in lane 8)
         if (NUMPY) {
             nd.normals(u, 0);                            // mcmc.py:387
@@ -1416,8 +1424,12 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
             const uint32_t blk = lane < 8 ? kTryBase + (uint32_t)lane : (lane == 8 ? 0u : (uint32_t)(lane - 8));
             dr.words(blk, w);
         }
-        pair_u0 = u53(w[0], w[1]);  // lanes 0-7: tries 2l, 2l+1; lane 8: U_thr, U_theta0
+        pair_u0 = u53(w[0], w[1]);  // lane 8: U_thr, U_theta0 (lanes 0-7: tries 4l .. 4l + 3, one word each -- try_w)
         pair_u1 = u53(w[2], w[3]);
+        try_w[0] = w[0];
+        try_w[1] = w[1];
+        try_w[2] = w[2];
+        try_w[3] = w[3];
         tangent_word = w[3];
         u_thr = lane_broadcast(pair_u0, 8);
         u_th0 = lane_broadcast(pair_u1, 8);
@@ -1498,13 +1510,10 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                 err |= GSSS_CHAIN_MAX_TRIES;
                 break;
             }
-            double tu0 = pair_u0, tu1 = pair_u1;
-            if (!NUMPY && t_base > 0) {  // 12 % of the steps: a further batch draws its own blocks
-                uint32_t w2[4];
-                dr.words(kTryBase + (uint32_t)(t_base >> 1) + (uint32_t)(lane & 7), w2);
-                tu0 = u53(w2[0], w2[1]);
-                tu1 = u53(w2[2], w2[3]);
-            }
+            // philox-v3: try t is word t % 4 of block kTryBase + t / 4; lane l < 8 holds block t_base / 4 + l (a batch reads lanes 0, 1)
+            uint32_t tw[4] = {try_w[0], try_w[1], try_w[2], try_w[3]};
+            if (!NUMPY && t_base > 0)  // 12 % of the steps: a further batch draws its own blocks
+                dr.words(kTryBase + (uint32_t)(t_base >> 2) + (uint32_t)(lane & 7), tw);
             // bracket recurrence, identical on every lane; lane t keeps theta_t
             double my_theta = 0.0;
             uint64_t my_sh = 0, my_sl = 0;  // numpy stream: generator state right after try t's uniform
@@ -1518,7 +1527,7 @@ __global__ void __launch_bounds__(kBlock) wave_kernel(TargetBlock tb, RunBlock a
                         my_sl = nd.sl;
                     }
                 } else {
-                    ut = lane_broadcast((t & 1) ? tu1 : tu0, t >> 1);
+                    ut = try_uniform((uint32_t)__builtin_amdgcn_readlane((int)tw[t & 3], t >> 2));
                 }
                 const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
                 if (lane == t) my_theta = theta;

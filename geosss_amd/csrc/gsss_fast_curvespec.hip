@@ -34,21 +34,21 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
     }
     // Round 5: dimensions that miss a whole number of quads per lane by at most one component per lane run the UNEVEN layout --
     // Q = 3 quads and one tail slot per lane (gsss_curvespec.h, R = 1) -- in the three-wavefront register class of the three-quad
-    // builds instead of four quads at two wavefronts: d = 49 .. 52 (BASELINE cfg4's d = 50), 97 .. 104, 193 .. 208 (cfg4's d = 200).
-    // Plain and replayed launches of curves of <= 10 knots; statistics builds keep the even layouts.  GSSS_CURVE_TAIL=0: off (A/B).
+    // builds instead of four quads at two wavefronts: d = 49 .. 52 (BASELINE cfg4's d = 50: 32.50 -> 27.23 ms per 10^8 chain-steps,
+    // +19 %) and 97 .. 104.  Sixteen-lane groups (d = 193 .. 208, cfg4's d = 200) LOSE with it (95.1 -> 106.7 ms: 264 B of scratch a
+    // lane against the 200 B of <16, 3, 10>) and keep four quads; GSSS_CURVE_TAIL=2 runs them for measurements, =0 turns the
+    // layout off.  Plain and replayed launches of curves of <= 10 knots; statistics builds keep the even layouts.
     if (tb.k <= 10 && (probe || rb.stats == nullptr)) {
-        static const bool tail = [] {
-            const char *e = getenv("GSSS_CURVE_TAIL");
-            return !(e && e[0] == '0');
-        }();
+        const char *env_tail = getenv("GSSS_CURVE_TAIL");  // (read per launch: tests switch it)
+        const int tail = env_tail ? atoi(env_tail) : 1;
 #define GSSS_SPEC_TAIL(LL)                                                                     \
     do {                                                                                       \
         if (probe) GSSS_PROBE(lane, "curvespec_kernel<%d, 3, 10, +1>", LL);                    \
         return do_curvespec<LL, 3, 10, 1>(tb, rb, replay, st);                                 \
     } while (0)
-        if (tail && tb.d > 48 && tb.d <= 52) GSSS_SPEC_TAIL(4);
-        if (tail && tb.d > 96 && tb.d <= 104) GSSS_SPEC_TAIL(8);
-        if (tail && tb.d > 192 && tb.d <= 208) GSSS_SPEC_TAIL(16);
+        if (tail >= 1 && tb.d > 48 && tb.d <= 52) GSSS_SPEC_TAIL(4);
+        if (tail >= 1 && tb.d > 96 && tb.d <= 104) GSSS_SPEC_TAIL(8);
+        if (tail >= 2 && tb.d > 192 && tb.d <= 208) GSSS_SPEC_TAIL(16);
 #undef GSSS_SPEC_TAIL
     }
     if (tb.d <= 16) GSSS_SPEC(4, 1);

@@ -34,9 +34,6 @@
 #ifndef GSSS_VMF_ONE_ALL
 #define GSSS_VMF_ONE_ALL 0  // (measurement: build it for every bucket; GSSS_ONE_PER_LANE=2 then runs it)
 #endif
-#ifndef GSSS_S2_TRY32
-#define GSSS_S2_TRY32 0  // (experiment, round 5: on S^2 a try's uniform is ONE 32-bit word of the stream, four tries per Philox block)
-#endif
 #ifndef GSSS_SCREEN_REGEN_THR
 #define GSSS_SCREEN_REGEN_THR 1  // (A/B: 0 parks the threshold uniform of the S^2 mixtures as round 2 did)
 #endif
@@ -959,10 +956,11 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
         }
     };
 
-    // up to two proposals, screened in single precision (one Philox block feeds a pair of tries: the first
-    // uniform of block j is try 2j, the second try 2j + 1) -- on S^2 (stream philox-v3) up to FOUR: a try's uniform is one 32-bit
-    // word, block j feeds tries 4j .. 4j + 3
-    constexpr bool kTry32 = D == 3 && !REPLAY && GSSS_S2_TRY32;
+    // up to FOUR proposals, screened in single precision: a try's uniform is one 32-bit word of the stream (philox-v3, round 5), block
+    // j feeds tries 4j .. 4j + 3.  (Rounds 2-4: two 53-bit uniforms a block, a pair of tries an attempt -- the Philox block was half of
+    // an attempt's cycles: README mixture 24.3 -> 20.7 ms per 10^9 chain-steps, K = 10 kappa = 500 46.8 -> 42.4, profiles/r05_ab_try32.log.)
+    // A replayed stream hands over doubles: two tries an attempt, as before.
+    constexpr bool kTry32 = !REPLAY;
     constexpr int kPerAttempt = kTry32 ? 4 : 2;
     auto attempt = [&]() {
         if (cur.t >= max_tries) {
@@ -987,7 +985,7 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
                 !(REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED))) {
                 double uu;
                 if constexpr (kTry32)
-                    uu = (double)w_try[h] * 0x1.0p-32;
+                    uu = try_uniform(w_try[h]);
                 else
                     uu = REPLAY ? replay_take() : u_pair[h & 1];
                 if (REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED)) {

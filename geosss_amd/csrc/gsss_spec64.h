@@ -226,17 +226,19 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
             dr.begin_step(a.step_offset + (uint64_t)s);
             uint32_t w[4];
             {
-                const int t = lane - nq;  // lanes past the normals: 0..7 the tries' blocks, the rest block 0
+                // lanes past the normals: 0..7 the tries' blocks, the rest block 0.  philox-v3: try i is word i % 4 of block
+                // try_base + i / 4 -- lane t publishes tries 2 t, 2 t + 1 as before: words 2 (t & 1), 2 (t & 1) + 1 of block try_base + t / 2
+                const int t = lane - nq;
                 const uint32_t blk = lane < nq ? 1u + (uint32_t)lane
-                                               : ((folded && t < kSpecPrefetched / 2) ? try_base + (uint32_t)t : 0u);
+                                               : ((folded && t < kSpecPrefetched / 2) ? try_base + (uint32_t)(t >> 1) : 0u);
                 dr.words(blk, w);
             }
             const double p0 = u53(w[0], w[1]), p1 = u53(w[2], w[3]);
             if (folded) {
                 const int t = lane - nq;
                 if (t >= 0 && t < kSpecPrefetched / 2) {
-                    scr[2 * t] = p0;
-                    scr[2 * t + 1] = p1;
+                    scr[2 * t] = try_uniform((t & 1) ? w[2] : w[0]);
+                    scr[2 * t + 1] = try_uniform((t & 1) ? w[3] : w[1]);
                 }
                 if (t == kSpecPrefetched / 2) {
                     scr[kSpecPrefetched] = p0;
@@ -255,11 +257,11 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
             }
             if (!folded) {  // d > 220: the tries' blocks and block 0 take a round of their own
                 uint32_t w2[4];
-                dr.words(lane < kSpecPrefetched / 2 ? try_base + (uint32_t)lane : 0u, w2);
+                dr.words(lane < kSpecPrefetched / 2 ? try_base + (uint32_t)(lane >> 1) : 0u, w2);
                 const double q0 = u53(w2[0], w2[1]), q1 = u53(w2[2], w2[3]);
                 if (lane < kSpecPrefetched / 2) {
-                    scr[2 * lane] = q0;
-                    scr[2 * lane + 1] = q1;
+                    scr[2 * lane] = try_uniform((lane & 1) ? w2[2] : w2[0]);
+                    scr[2 * lane + 1] = try_uniform((lane & 1) ? w2[3] : w2[1]);
                 }
                 if (lane == kSpecPrefetched / 2) {
                     scr[kSpecPrefetched] = q0;
@@ -334,14 +336,12 @@ __global__ void __launch_bounds__(kBlock) curve64_kernel(TargetBlock tb, RunBloc
             } else if (t_base < kSpecPrefetched) {
 #pragma unroll
                 for (int q = 0; q < kSpecRows; ++q) ut[q] = scr[t_base + q];
-            } else {  // rare: past the prefetched tries, two more blocks per batch
+            } else {  // rare: past the prefetched tries, one more block per batch of four (every lane forms the same one)
+                static_assert(kSpecRows == 4, "a batch is one block of the stream");
                 uint32_t w2[4];
-                dr.words(try_base + (uint32_t)(t_base >> 1) + (uint32_t)(lane >> 5), w2);
-                const double q0 = u53(w2[0], w2[1]), q1 = u53(w2[2], w2[3]);
-                ut[0] = lane_broadcast(q0, 0);
-                ut[1] = lane_broadcast(q1, 0);
-                ut[2] = lane_broadcast(q0, 32);
-                ut[3] = lane_broadcast(q1, 32);
+                dr.words(try_base + (uint32_t)(t_base >> 2), w2);
+#pragma unroll
+                for (int q = 0; q < kSpecRows; ++q) ut[q] = try_uniform(w2[q]);
             }
             double my_theta = 0.0;
 #pragma unroll

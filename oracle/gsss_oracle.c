@@ -524,7 +524,7 @@ typedef struct {
     uint64_t seed, chain, step;
     int d;
     int64_t try_idx;
-    double cached;
+    uint32_t cached[4]; /* the words of the try block in use */
 } gor_draws;
 
 static double gor_take(gor_draws *g)
@@ -598,18 +598,20 @@ static void gor_draw_step_uniforms(gor_draws *g, double *u_thr, double *u_theta0
     *u_theta0 = u[1];
 }
 
-/* the uniform of try number `g->try_idx` (mcmc.py:395) */
+/* the uniform of try number `g->try_idx` (mcmc.py:395).  Library stream (philox-v3, round 5): ONE 32-bit word per try -- try t
+ * is word t % 4 of block 1 + nb + t / 4, u = w / 2^32, so theta = lo + (hi - lo) u keeps 32 bits of resolution RELATIVE to the
+ * bracket however far it has shrunk (rounds 1-4, philox-v2: two 53-bit uniforms a block; half the blocks now -- the try
+ * loop of the lane kernels is to a third Philox arithmetic) */
 static double gor_draw_try(gor_draws *g)
 {
     if (g->pcg) return gor_npy_double(g->pcg);
     if (g->replay) return gor_take(g);
     int64_t t = g->try_idx++;
-    if (t & 1) return g->cached;
-    double u[2];
-    uint32_t nb = (uint32_t)((g->d + 3) / 4);
-    gor_stream_block(g->seed, g->chain, g->step, 1u + nb + (uint32_t)(t >> 1), u);
-    g->cached = u[1];
-    return u[0];
+    if ((t & 3) == 0) {
+        uint32_t nb = (uint32_t)((g->d + 3) / 4);
+        gor_stream_words(g->seed, g->chain, g->step, 1u + nb + (uint32_t)(t >> 2), g->cached);
+    }
+    return (double)g->cached[t & 3] * 0x1.0p-32;
 }
 
 /* ------------------------------------------------------------------ mcmc.py */

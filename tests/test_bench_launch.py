@@ -30,7 +30,7 @@ def test_line_fits():
     import bench
     recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_full.json"))) or [os.path.join(ROOT, "profiles", "r04_bench_default.json")]
     full = json.load(open(recs[-1]))
-    full["config"].setdefault("stream_short", "philox-v2 (chain,step)-keyed; S2: tangent = one 32-bit angle")
+    full["config"].setdefault("stream_short", "philox-v3 (chain,step)-keyed; S2: tangent = one angle; 32-bit tries")
     full["config"].setdefault("thin", 100)
     for c in full["configs"]:
         c.setdefault("name", c["workload"].split(":")[0] + ("__numpy_stream" if "rng=numpy" in c["workload"] else ""))
@@ -98,7 +98,7 @@ def test_two_ranks_end_to_end_on_one_gpu():
     kr = out["rccl"]["kernel_ms_per_rank"]
     assert len(kr["all"]) == 2 and 0 < kr["min"] <= kr["max"] and out["rccl"]["gather_ms"] > 0
     assert 0 < out["rccl"]["wall_ms_per_rank"]["min"] <= out["rccl"]["wall_ms_per_rank"]["max"]
-    assert "philox-v2" in out["config"]["stream"] and len(line[0]) < 6000
+    assert "philox-v3" in out["config"]["stream"] and len(line[0]) < 6000
     full = json.load(open(os.path.join(ROOT, out["full_record"])))
     assert "meaning" in full["roofline_valu"] and full["value"] == pytest.approx(out["value"], rel=1e-5)
     # cfg5's own workload timed on every rank of a multi-rank run (a smaller ensemble here: --chains applies to the headline only)
