@@ -97,6 +97,14 @@ __host__ __device__ constexpr bool curvespec_parks_u()
 {
     return Q >= 2 && (NK > 10 || HEAVY || Q >= GSSS_CS_PARK_FROM_Q || (Q == 3 && GSSS_CS_WAVES_Q3 >= 3));
 }
+// (R) the tail slot of the tangent rests in LDS beside the quads' -- but for sixteen-lane groups: with its 2 KB the <16, 3, 10, +1>
+// workgroup needs 55.8 KB of LDS, TWO workgroups per CU under a kernel built for three wavefronts per SIMD (the first measurement of
+// that build: 95.1 -> 106.7 ms at d = 200); without, 53.7 KB: three
+template <int L, int R>
+__host__ __device__ constexpr bool curvespec_parks_tail()
+{
+    return R > 0 && L < 16;
+}
 template <int L, int Q, int NK, bool STATS>
 __host__ __device__ constexpr int curvespec_waves()
 {
@@ -109,7 +117,7 @@ __host__ __device__ constexpr size_t curvespec_lds_doubles()
 {
     return (size_t)NK * (4 * Q * L + R * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
            (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2 +
-           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)(4 * Q + R) * kBlock : 0);
+           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)(4 * Q + (curvespec_parks_tail<L, R>() ? 1 : 0)) * kBlock : 0);
 }
 
 // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397), FastCurve::level
@@ -240,6 +248,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
     // Q >= 2 (d > 64): u is only needed again when the chain moves; its 8 Q registers are lent to the try loop meanwhile
     // (slots 2 p, 2 p + 1 of thread t at [p][t][2]: 16-byte accesses, conflict-free)
     constexpr bool kParkU = curvespec_parks_u<Q, NK, REPLAY || STATS>();
+    constexpr bool kParkT = kParkU && curvespec_parks_tail<L, R>();
     double2 *upark = reinterpret_cast<double2 *>(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2) + threadIdx.x;
     double *upark_t = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2 + (size_t)N * kBlock + threadIdx.x;  // (R: the tail slot's)
     Scalar sc;
@@ -524,7 +533,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             }
             if (R) {
                 ut *= rnw;
-                if (kParkU) upark_t[0] = ut;
+                if (kParkT) upark_t[0] = ut;
             }
         }
         wave_sync();  // (one synchronisation for the step's uniforms, the parked coefficients and u)
@@ -671,7 +680,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                     x[i] = fma(sn, up.x, cs * x[i]);
                     x[i + 1] = fma(sn, up.y, cs * x[i + 1]);
                 }
-                if (R) xt = fma(sn, upark_t[0], cs * xt);
+                if (R) xt = fma(sn, kParkT ? upark_t[0] : ut, cs * xt);
             } else {
 #pragma unroll
                 for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
