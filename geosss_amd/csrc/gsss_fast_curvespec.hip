@@ -34,10 +34,14 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
     }
     // Round 5: dimensions that miss a whole number of quads per lane by at most one component per lane run the UNEVEN layout --
     // Q = 3 quads and one tail slot per lane (gsss_curvespec.h, R = 1) -- in the three-wavefront register class of the three-quad
-    // builds instead of four quads at two wavefronts: d = 49 .. 52 (BASELINE cfg4's d = 50: 32.50 -> 27.23 ms per 10^8 chain-steps,
-    // +19 %) and 97 .. 104.  Sixteen-lane groups (d = 193 .. 208, cfg4's d = 200) LOSE with it (95.1 -> 106.7 ms: 264 B of scratch a
-    // lane against the 200 B of <16, 3, 10>) and keep four quads; GSSS_CURVE_TAIL=2 runs them for measurements, =0 turns the
-    // layout off.  Plain and replayed launches of curves of <= 10 knots; statistics builds keep the even layouts.
+    // builds instead of four quads at two wavefronts.  Measured, ms per 10^8 chain-steps (profiles/r05_ab_curve_tail.log):
+    //   d = 49 .. 52   <4, 3, 10, +1>   d = 50 (BASELINE cfg4): 32.50 -> 27.23 (+19 %)
+    //   d = 97 .. 104  <8, 3, 10, +1>   d = 100: 52.15 -> 44.01 (+18 %)
+    //   d = 193 .. 208 <16, 3, 10, +1>  d = 200 (cfg4): 94.03 -> 80.45 (+17 %) -- with the tail slot of the tangent kept in a register:
+    //                                   parked in LDS like the quads' the workgroup needs 55.8 KB, two workgroups per CU under a
+    //                                   kernel built for three wavefronts per SIMD: 106.7 ms
+    // GSSS_CURVE_TAIL=0 turns the layout off (A/B).  Plain and replayed launches of curves of <= 10 knots; statistics builds keep
+    // the even layouts.
     if (tb.k <= 10 && (probe || rb.stats == nullptr)) {
         const char *env_tail = getenv("GSSS_CURVE_TAIL");  // (read per launch: tests switch it)
         const int tail = env_tail ? atoi(env_tail) : 1;
@@ -48,7 +52,7 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
     } while (0)
         if (tail >= 1 && tb.d > 48 && tb.d <= 52) GSSS_SPEC_TAIL(4);
         if (tail >= 1 && tb.d > 96 && tb.d <= 104) GSSS_SPEC_TAIL(8);
-        if (tail >= 2 && tb.d > 192 && tb.d <= 208) GSSS_SPEC_TAIL(16);
+        if (tail >= 1 && tb.d > 192 && tb.d <= 208) GSSS_SPEC_TAIL(16);
 #undef GSSS_SPEC_TAIL
     }
     if (tb.d <= 16) GSSS_SPEC(4, 1);

@@ -387,8 +387,9 @@ SYNTH = [("vmf", 11, 6), ("vmf", 13, 4), ("vmf", 14, 2), ("vmf", 12, 7), ("vmf",
          ("curve", 64, 11), ("curve", 65, 10), ("curve", 128, 5), ("curve", 129, 10), ("curve", 192, 17), ("curve", 193, 10),
          ("curve", 256, 10), ("curve", 4, 10), ("curve", 5, 3), ("curve", 8, 10),
          # round 5, the uneven layouts (three quads + one tail component per lane): d = 49 .. 52 in four-lane groups, 97 .. 104 in
-         # eight-lane groups -- one tail component, a full tail (every lane's slot taken: block 0 and the tries get a round of their own)
+         # eight-lane groups, 193 .. 208 in sixteen-lane groups -- one tail component, a full tail (every lane's slot taken: block 0 and the tries get a round of their own)
          ("curve", 49, 10), ("curve", 51, 7), ("curve", 52, 10), ("curve", 97, 10), ("curve", 101, 3), ("curve", 104, 10),
+         ("curve", 200, 10), ("curve", 205, 4), ("curve", 208, 10),   # (193: above, with the layout boundaries)
          # cooperative mixture kernels: slots per lane 4 | 8 | 16 at d = 64 | 65, 128 | 129; up to 256
          ("vmf", 64, 3), ("vmf", 65, 5), ("vmf", 128, 3), ("vmf", 129, 2), ("vmf", 256, 16)]
 
@@ -437,24 +438,23 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k, monkeypatch):
     assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
 
 
-@pytest.mark.parametrize("d,k", [(193, 10), (200, 10), (205, 4), (208, 10)])
-def test_uneven_sixteen_lane_layout_matches_oracle(gs, oracle, d, k, monkeypatch):
-    """curvespec_kernel<16, 3, 10, +1> (d = 193 .. 208): measured BEHIND four quads per lane at d = 200 (profiles/r05_ab_curve_tail.log),
-    so the library does not pick it -- GSSS_CURVE_TAIL=2 does, and the build is held to the oracle like every other one."""
-    monkeypatch.setenv("GSSS_CURVE_TAIL", "2")
+@pytest.mark.parametrize("d,k,even", [(50, 10, "curvespec_kernel<4, 4, 10"), (100, 7, "curvespec_kernel<8, 4, 10"), (200, 10, "curvespec_kernel<16, 4, 10")])
+def test_even_layouts_behind_the_switch_match_oracle(gs, oracle, d, k, even, monkeypatch):
+    """GSSS_CURVE_TAIL=0: the four-quad builds the uneven layouts replaced at d = 49 .. 52, 97 .. 104, 193 .. 208 are still what
+    statistics launches of those dimensions run, and what the A/B of profiles/r05_ab_curve_tail.log timed: held to the oracle too."""
     knots = gs.brownian_curve(k, d, 0.5, seed=d)
     pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 300.0)
     tgt = oracle.Target.curve_vmf(knots, 300.0)
     n_chains, n_steps = 70, 12
     x0 = oracle.sample_sphere(3, n_chains, d)
     want = oracle.run(tgt, x0, n_steps, seed=77, n_threads=8)
+    assert _packed_kernel(gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement="packed")).endswith("3, 10, +1>")
+    monkeypatch.setenv("GSSS_CURVE_TAIL", "0")
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement="packed")
-    assert _packed_kernel(s) == "curvespec_kernel<16, 3, 10, +1>"
+    assert _packed_kernel(s).startswith(even)
     kept = s.advance(n_steps, thin=1).permute(2, 0, 1).cpu().numpy()
     assert np.all(s.errors == 0) and np.array_equal(s.n_tries_per_chain, want["n_tries"])
     assert np.max(np.abs(kept - want["samples"])) < TOL
-    monkeypatch.setenv("GSSS_CURVE_TAIL", "0")
-    assert _packed_kernel(gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement="packed")).startswith("curvespec_kernel<16, 4, 10")
 
 
 @pytest.mark.parametrize("d", [129, 150, 256, 400])
