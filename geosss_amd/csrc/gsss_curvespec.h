@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 }
                 wave_sync();
             } else {
-                while (t_base + L > pref) {  // (wave-uniform) another round: lane g draws the tries' block pref / 2 + g
+                while (t_base + L > pref) {  // (wave-uniform) another round: lane g draws the tries' block pref / 4 + g (four tries a block)
                     uint32_t w[4];
                     dr.words(try_base + (uint32_t)(pref >> 2) + (uint32_t)g, w);
                     publish_extra(1 + (pref >> 2) + g, w);

@@ -128,7 +128,9 @@ typedef struct gsss_target_desc {
  * (DESIGN.md §3 "Random streams").  On this stream a step draws d normals for the tangent direction as the reference does
  * (mcmc.py:387; Box-Muller pairs formed in single precision: they only set a direction) -- except on S^2 (d = 3), where the uniformly distributed unit tangent is drawn directly as one angle in
  * the tangent plane and one block carries the whole set-up of a step (same law; the two sources below keep the reference's
- * normals and draw order).
+ * normals and draw order).  The uniform of a try (mcmc.py:395) is ONE 32-bit word of the stream, u = w / 2^32 -- try t is word t % 4
+ * of block 1 + ceil(d / 4) + t / 4 ("philox-v3"; theta = lo + (hi - lo) u keeps 32 bits of resolution relative to the bracket
+ * however far it has shrunk) -- the threshold uniform (mcmc.py:389) has 53 bits.
  * If replay_dev is non-NULL the draws are read from it instead:
  * per chain `replay_stride` doubles in the order the reference consumes them
  * (d normals, u_threshold, [u_theta0,] u_try, u_try, ... ; next step ...) -- this is how the
