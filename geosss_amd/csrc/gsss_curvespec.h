@@ -437,7 +437,12 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             // same products in the same order, the same bits).  The two-wavefront builds wait on LDS with nobody to switch to (vector
             // pipes 0.83 busy): d = 24 28.60 -> 28.20 ms, d = 50 34.87 -> 33.96, d = 200 97.8 -> 95.96 per 10^8 chain-steps
             // (profiles/r04_ab_knot_pipeline.log; scheduling barriers every 1 / 3 / 5 knots or none: 0 .. +3 %, left at 2).
-            constexpr bool kPipe = GSSS_CS_KNOT_PIPE && Q >= 2;
+            // Round 5: NOT in the three-quad builds at three wavefronts per SIMD -- there a stalled wavefront has two others to
+            // switch to, and the row held ahead costs 48 .. 88 B of scratch a lane: at d = 200 the resident wavefronts' scratch falls
+            // from 5.9 to 3.7 MB per XCD, under the 4 MB of its L2 (34.2 -> 8.3 GB of HBM traffic per launch, 80.3 -> 74.1 ms); d = 50
+            // 4.19 -> 2.25 GB, 26.0 -> 25.4 ms; d = 40 / 100 / 160 +0.5 .. 1.3 %, d = 80 -0.8 % (profiles/r05_ab_knot_pipe_q3.log).
+            // Two quads (three wavefronts, d = 24: -1 % without) and four quads (two wavefronts) keep it.
+            constexpr bool kPipe = GSSS_CS_KNOT_PIPE && Q >= 2 && !(Q == 3 && curvespec_waves<L, Q, NK, STATS>() >= 3 && !REPLAY);
             if constexpr (kPipe) {
                 // (sixteen lanes x sixteen components: half a row ahead -- a whole one spills 12 bytes a lane at two wavefronts per SIMD)
                 constexpr int kAhead = (L >= 16 && Q >= 4) ? N / 4 : N / 2;
