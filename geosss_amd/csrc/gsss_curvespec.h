@@ -78,6 +78,9 @@ namespace gsss {
 #ifndef GSSS_CS_KNOT_PIPE
 #define GSSS_CS_KNOT_PIPE 1  // knot rows read from LDS one row ahead of their products (more than four components per lane)
 #endif
+#ifndef GSSS_CS_KNOT_PIPE_Q3
+#define GSSS_CS_KNOT_PIPE_Q3 0  // (A/B: 1 = the pipeline in the three-quad builds at three wavefronts per SIMD too, as before round 5)
+#endif
 #ifndef GSSS_CS_KNOT_BARRIER
 #define GSSS_CS_KNOT_BARRIER 2  // knots between scheduling barriers in the knot-dot loop
 #endif
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             // from 5.9 to 3.7 MB per XCD, under the 4 MB of its L2 (34.2 -> 8.3 GB of HBM traffic per launch, 80.3 -> 74.1 ms); d = 50
             // 4.19 -> 2.25 GB, 26.0 -> 25.4 ms; d = 40 / 100 / 160 +0.5 .. 1.3 %, d = 80 -0.8 % (profiles/r05_ab_knot_pipe_q3.log).
             // Two quads (three wavefronts, d = 24: -1 % without) and four quads (two wavefronts) keep it.
-            constexpr bool kPipe = GSSS_CS_KNOT_PIPE && Q >= 2 && !(Q == 3 && curvespec_waves<L, Q, NK, STATS>() >= 3 && !REPLAY);
+            constexpr bool kPipe = GSSS_CS_KNOT_PIPE && Q >= 2 && !(Q == 3 && curvespec_waves<L, Q, NK, STATS>() >= 3 && !REPLAY && !GSSS_CS_KNOT_PIPE_Q3);
             if constexpr (kPipe) {
                 // (sixteen lanes x sixteen components: half a row ahead -- a whole one spills 12 bytes a lane at two wavefronts per SIMD)
                 constexpr int kAhead = (L >= 16 && Q >= 4) ? N / 4 : N / 2;
@@ -514,6 +517,11 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                             pu = fma(kv.y, u[i + 1], pu);
                             if (refresh) px = fma(kv.y, x[i + 1], px);
                         }
+                    }
+                    if (R) {  // the row's tail slot
+                        const double kt = row[DMAIN + g];
+                        pu = fma(kt, ut, pu);
+                        if (refresh) px = fma(kt, xt, px);
                     }
                     const double au = group_sum<L>(pu) * rnw;
                     const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
