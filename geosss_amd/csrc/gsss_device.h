@@ -55,6 +55,9 @@ struct RunBlock {
     const double *stats_dirs;  // [2 + stats_modes][d]: projection w, hop direction h, mode directions
     int32_t stats_lags, stats_modes;
     int32_t stats_flags;       // GSSS_STATS_* (row layout of `stats`)
+    int32_t stats_onchip;      // lane kernels, one chain per lane: 1 = a launch's statistics on chip (StatsLane: the accumulators and
+                               // lag sums in registers, the ring of the last stats_lags projections in LDS); 0 = every draw
+                               // read-modify-writes its rows in HBM (stats_update)
     // Slice scheduling (kernels that support it; NULL: one workgroup per chunk of chains runs the whole launch).  A launch whose
     // chunks do not fit the chip at once runs its last, partial round of workgroups on a nearly empty chip; sliced, the grid has
     // one workgroup per (chunk, step slice), every workgroup draws its item from a ticket counter, slice-major, and a chunk's
@@ -360,6 +363,184 @@ __device__ __forceinline__ void stats_update(const RunBlock &a, int64_t c, const
     }
     s[0] = (double)(cnt + 1);
 }
+
+// ------------------------------------------------------------------------------------------
+// Round 5: the same statistics with a LAUNCH's working set on chip (lane kernels, one chain per lane).  stats_update above
+// read-modify-writes every row a draw touches in HBM, the L lag sums in a loop of dependent round trips: with one wavefront per
+// SIMD (a statistics build's occupancy) a launch that accumulates every state is 28 x slower than the plain kernel -- 0.78 of the
+// HBM peak at 32 lags (6.2 TB/s, profiles/r05_stats_thin1_lags32_summary.md), latency-bound beyond (64 lags: 160 us a draw).
+// Here a lane takes its chain's accumulators INTO REGISTERS when it takes the chain up -- the moments, the L <= kStatsMaxLags lag
+// sums (128 of the 512 registers a one-wavefront build may use) -- and the ring of the last L projections into LDS (where a second
+// chain would be parked), and writes them back when it lets go of the chain (end of the launch or slice).  A draw then costs L
+// LDS reads and L multiply-adds and no HBM traffic but the mode count.
+// THE SAME BITS as stats_update: every accumulator sees the same operations in the same order, so the rows in HBM are the
+// ones stats_update leaves -- any mix of the two over launches, slices and kernel families continues the same series.
+// ------------------------------------------------------------------------------------------
+constexpr int kStatsMaxLags = 64;
+
+template <int D>
+struct StatsLane {
+    static constexpr int kT = D * (D + 1) / 2;
+    static constexpr bool kXXRegs = D <= 6;  // the second moments in registers (21 at d = 6); beyond, read-modify-written per draw as before
+    int64_t cnt;
+    int pos;            // ring slot of the NEXT draw: cnt % L (the slot its row in HBM has: draw t rests in ring row t % L)
+    double prev[D], sum[D], xx[kXXRegs ? kT : 1];
+    double dist, hop, psum, psq;
+    double lag[kStatsMaxLags];
+    double *ring;       // LDS, this lane's slot j at ring[j * kBlock]
+
+    struct Rows {
+        int r_prev, r_sum, r_xx, r_dist, r_hop, r_mode, r_p, r_lag, r_ring, r_head, K, L, T;
+        bool second;
+    };
+    __device__ __forceinline__ Rows rows(const RunBlock &a) const
+    {
+        Rows r;
+        r.K = a.stats_modes;
+        r.L = a.stats_lags;
+        r.second = !(a.stats_flags & GSSS_STATS_NO_SECOND_MOMENT);
+        r.T = r.second ? kT : 0;
+        r.r_prev = 1;
+        r.r_sum = 1 + D;
+        r.r_xx = 1 + 2 * D;
+        r.r_dist = r.r_xx + r.T;
+        r.r_hop = r.r_dist + 1;
+        r.r_mode = r.r_hop + 1;
+        r.r_p = r.r_mode + r.K;
+        r.r_lag = r.r_p + 2;
+        r.r_ring = r.r_lag + r.L;
+        r.r_head = r.r_ring + r.L;
+        return r;
+    }
+
+    __device__ __forceinline__ void load(const RunBlock &a, int64_t c, double *ring_lds)
+    {
+        const size_t n = (size_t)a.n_chains;
+        const double *s = a.stats + c;
+        const Rows r = rows(a);
+        ring = ring_lds;
+        cnt = (int64_t)s[0];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            prev[i] = s[(size_t)(r.r_prev + i) * n];
+            sum[i] = s[(size_t)(r.r_sum + i) * n];
+        }
+        if (kXXRegs && r.second) {
+#pragma unroll
+            for (int t = 0; t < kT; ++t) xx[t] = s[(size_t)(r.r_xx + t) * n];
+        }
+        dist = s[(size_t)r.r_dist * n];
+        hop = s[(size_t)r.r_hop * n];
+        psum = s[(size_t)r.r_p * n];
+        psq = s[(size_t)(r.r_p + 1) * n];
+        pos = r.L > 0 ? (int)(cnt % (int64_t)r.L) : 0;
+#pragma unroll
+        for (int l = 0; l < kStatsMaxLags; ++l) {
+            const bool in = l < r.L;
+            lag[l] = in ? s[(size_t)(r.r_lag + (in ? l : 0)) * n] : 0.0;
+            if (in) ring[(size_t)l * kBlock] = s[(size_t)(r.r_ring + l) * n];
+        }
+    }
+
+    __device__ __forceinline__ void draw(const RunBlock &a, int64_t c, const double (&x)[D])
+    {
+        const size_t n = (size_t)a.n_chains;
+        double *s = a.stats + c;
+        const Rows r = rows(a);
+        const double *w = a.stats_dirs, *h = a.stats_dirs + D, *modes = a.stats_dirs + 2 * D;
+        double p = 0.0, xh = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            p = fma(x[j], w[j], p);
+            xh = fma(x[j], h[j], xh);
+        }
+        if (cnt > 0) {
+            double dot = 0.0, ph = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                dot = fma(prev[j], x[j], dot);
+                ph = fma(prev[j], h[j], ph);
+            }
+            dist += acos(fmin(fmax(dot, -1.0), 1.0));
+            const int sa = (xh > 0.0) - (xh < 0.0), sb = (ph > 0.0) - (ph < 0.0);  // np.sign
+            if (sa != sb) hop += 1.0;
+        }
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            prev[i] = x[i];
+            sum[i] += x[i];
+            if (r.second) {
+#pragma unroll
+                for (int j = i; j < D; ++j) {
+                    if (kXXRegs)
+                        xx[t] += x[i] * x[j];
+                    else
+                        s[(size_t)(r.r_xx + t) * n] += x[i] * x[j];
+                    ++t;
+                }
+            }
+        }
+        if (r.K > 0) {
+            int best = 0;
+            double bv = -INFINITY;
+            for (int k = 0; k < r.K; ++k) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) v = fma(x[j], modes[k * D + j], v);
+                if (v > bv) {  // first maximum, like np.argmax
+                    bv = v;
+                    best = k;
+                }
+            }
+            s[(size_t)(r.r_mode + best) * n] += 1.0;
+        }
+        psum += p;
+        psq += p * p;
+        if (r.L > 0) {
+            const int lm = cnt < (int64_t)r.L ? (int)cnt : r.L;  // lags this draw has a partner for
+            int si = pos;                                        // draw cnt - l rests in slot (pos - l) mod L
+#pragma unroll
+            for (int l = 1; l <= kStatsMaxLags; ++l) {
+                si = si == 0 ? r.L - 1 : si - 1;
+                if (l <= lm) lag[l - 1] += p * ring[(size_t)si * kBlock];
+            }
+            ring[(size_t)pos * kBlock] = p;
+            if (cnt < r.L) s[(size_t)(r.r_head + cnt) * n] = p;
+            pos = pos + 1 == r.L ? 0 : pos + 1;
+        }
+        ++cnt;
+    }
+
+    // everything back where stats_update keeps it
+    __device__ __forceinline__ void store(const RunBlock &a, int64_t c)
+    {
+        const size_t n = (size_t)a.n_chains;
+        double *s = a.stats + c;
+        const Rows r = rows(a);
+        s[0] = (double)cnt;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            s[(size_t)(r.r_prev + i) * n] = prev[i];
+            s[(size_t)(r.r_sum + i) * n] = sum[i];
+        }
+        if (kXXRegs && r.second) {
+#pragma unroll
+            for (int t = 0; t < kT; ++t) s[(size_t)(r.r_xx + t) * n] = xx[t];
+        }
+        s[(size_t)r.r_dist * n] = dist;
+        s[(size_t)r.r_hop * n] = hop;
+        s[(size_t)r.r_p * n] = psum;
+        s[(size_t)(r.r_p + 1) * n] = psq;
+#pragma unroll
+        for (int l = 0; l < kStatsMaxLags; ++l) {
+            if (l < r.L) {
+                s[(size_t)(r.r_lag + l) * n] = lag[l];
+                s[(size_t)(r.r_ring + l) * n] = ring[(size_t)l * kBlock];
+            }
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // RNG stream (DESIGN.md §3 "Random streams"): Philox4x32-10, counter = (block, step_lo, chain_lo,

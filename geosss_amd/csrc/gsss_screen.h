@@ -829,6 +829,10 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
     Chain cur;
     int32_t slot = 0;
     int32_t parked_status = kDone;
+    // STATS, one chain per lane: the chain's running statistics on chip for the launch (StatsLane, gsss_device.h) -- the ring of
+    // its last projections where a second chain would be parked
+    StatsLane<D> sl;
+    const bool stats_onchip = STATS && a.stats_onchip > 0;
 
     auto chain_id = [&]() { return slot ? id1 : id0; };
     auto philox = [&]() {
@@ -872,6 +876,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
         cur.t = 0;
         cur.status = (valid && n_steps > s_begin) ? kPending : kDone;
         if constexpr (NUMPY) nd.init(a, cc, D);
+        if constexpr (STATS) {
+            if (stats_onchip && valid) sl.load(a, cc, reinterpret_cast<double *>(park));
+        }
         if (sliced && valid) {
             if (SliceSched::dead(a, a.one_per_lane ? kBlock : kChunk)[cc] != 0) cur.status = kDone;  // stopped with an error flag in an earlier slice
             if (timed_out && cur.status != kDone) {                             // cannot happen (SliceSched::take)
@@ -1077,7 +1084,12 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
                         for (int j = 0; j < D; ++j) a.samples[sample_index(a, cur.row, j, D, chain_id())] = cur.x[j];
                     }
                 }
-                if constexpr (STATS) stats_update<D>(a, chain_id(), cur.x);
+                if constexpr (STATS) {
+                    if (stats_onchip)
+                        sl.draw(a, chain_id(), cur.x);
+                    else
+                        stats_update<D>(a, chain_id(), cur.x);
+                }
                 ++cur.row;
             }
             const bool exhausted = REPLAY && (cur.err & GSSS_CHAIN_REPLAY_EXHAUSTED);
@@ -1158,6 +1170,9 @@ __global__ void __launch_bounds__(kBlock, (STATS || (REPLAY && !NUMPY)) ? 1 : (N
         // every move, where it names the LAST kept row until the next one is due)
         if (kStageP > 1 && n_staged > 0) unstage(&a.samples[sample_index(a, cur.steps_done / thin, 0, D, c)]);
         if constexpr (NUMPY) nd.finish(a, c, true);
+        if constexpr (STATS) {
+            if (stats_onchip) sl.store(a, c);
+        }
 #pragma unroll
         for (int j = 0; j < D; ++j) put_out(&a.state[(size_t)j * n + c], cur.x[j]);
         if (a.n_reject) put_out(&a.n_reject[c], a.n_reject[c] + ((int64_t)cur.n_try - (cur.steps_done - s_begin)));
@@ -1336,10 +1351,27 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     if constexpr (!REPLAY && TP::kStageRows && D <= 10) {
         if (TP::kPreferOne && !(env_one && env_one[0] == '0') && rb.stats == nullptr) one_per_lane = true;
     }
+    // Running statistics (round 5): one chain per lane with the launch's working set on chip -- the accumulators and the lag sums
+    // in registers, the ring of the last L projections in the LDS a parked chain would take (StatsLane, gsss_device.h: the same
+    // bits as the per-draw read-modify-write) -- for L <= kStatsMaxLags lags, wherever the ring fits the LDS.
+    // GSSS_STATS_ONCHIP=0: the per-draw path (A/B, tests).
+    int32_t stats_onchip = 0;
+    size_t stats_ring = 0;  // doubles of LDS
+    if constexpr (!REPLAY) {
+        const char *env_st = getenv("GSSS_STATS_ONCHIP");
+        if (rb.stats != nullptr && !(env_st && env_st[0] == '0') && rb.stats_lags <= kStatsMaxLags) {
+            const size_t ring = (size_t)rb.stats_lags * kBlock;
+            if ((TP::lds_doubles() + kTabLds + ring) * sizeof(double) <= (size_t)160 * 1024) {  // (a workgroup's LDS on gfx950)
+                stats_onchip = 1;
+                stats_ring = ring;
+                one_per_lane = true;
+            }
+        }
+    }
     bool stage_rows = false;
     if (one_per_lane) {
         per_block = kBlock;
-        lds = (TP::lds_doubles() + kTabLds) * sizeof(double);  // nothing is parked: the workgroup needs no LDS for it
+        lds = (TP::lds_doubles() + kTabLds + stats_ring) * sizeof(double);  // nothing is parked: no LDS for it (statistics: the ring)
         // A build of the kernel for ONE chain per lane (screened_kernel<.., STAGE>: no code for a parked chain -- Bingham d = 10: 154
         // instead of 143 registers, but nothing of the trade logic in the loop: 10^6 chains, 39.3 -> 36.85 ms, ahead of two chains
         // per lane at 37.45), which for the Bingham targets (TP::kHoldRows) also holds chain-major retained rows that are not whole
@@ -1379,6 +1411,7 @@ int do_screened_run(const TargetBlock &tb, const RunBlock &rb, hipStream_t st)
     plan = plan_partial_round(kern, lds, rb, n_chunks, !REPLAY && screen_parks<D, TP>(), st, first);
     RunBlock rbl = rb;
     rbl.one_per_lane = one_per_lane ? 1 : 0;
+    rbl.stats_onchip = stats_onchip;
     rbl.stage_rows = stage_rows ? 1 : 0;
     rbl.sched = plan.ws;
     rbl.slice_steps = plan.slice_steps;

@@ -429,3 +429,37 @@ def test_between_chain_tau_agrees_with_the_windowed_estimators(gs, name, thin, b
     assert abs(tau_between / tau_pooled - 1.0) < 0.05, (tau_between, tau_pooled)
     assert 0.85 < tau_between / tau_per_chain <= 1.02, (tau_between, tau_per_chain)
     assert bc["rel_se"] < 0.004 and bc["chains"] == n
+
+
+@pytest.mark.parametrize("name,lags,second", [("vmfmix_readme", 32, True), ("vmfmix_readme", 0, True), ("vmfmix_readme", 5, False), ("vmfmix_k10_kappa500", 64, True),
+                                              ("bingham_d10_vmax30", 64, False), ("bingham_d10_vmax30", 8, True), ("bingham_d5_dense", 17, True),
+                                              ("vmfmix_d10_k5_kappa100", 40, None)])
+def test_statistics_on_chip_equal_the_per_draw_rows(gs, name, lags, second, monkeypatch):
+    """Round 5: a statistics launch of the lane kernels keeps its working set on chip (StatsLane, gsss_device.h: accumulators in
+    registers, the ring of the last L projections in LDS, the lag sums folded eight draws at a time) instead of read-modify-writing
+    every row in HBM for every draw -- THE SAME BITS, because every accumulator sees the same operations in the same order: the
+    rows it leaves in HBM equal the per-draw path's (GSSS_STATS_ONCHIP=0) bit for bit, over launches of ragged lengths (blocks
+    cut at launch ends, counts below L, rings that wrap), thinning, and launches that alternate between the two paths."""
+    import torch
+    from conftest import golden
+    from helpers import product_target
+    z = golden(f"traj_{name}.npz")
+    pdf = product_target(z)
+    d = len(z["x0"])
+    n = 3000
+    x0 = gs.sample_sphere_device(d - 1, n, seed=21).T
+    launches = [(3, 1), (70, 1), (9, 3), (131, 2), (64, 1), (300, 7), (1, 1), (257, 1)]
+
+    def run(paths):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=31, mode="fast", placement="packed").enable_stats(lags=lags, second_moment=second)
+        for i, (steps, thin) in enumerate(launches):
+            monkeypatch.setenv("GSSS_STATS_ONCHIP", paths[i % len(paths)])
+            s.advance(steps, thin=thin, keep=False)
+        torch.cuda.synchronize()
+        return s._stats["acc"].clone(), s.state_device.clone(), s._n_tries.clone()
+
+    per_draw, on_chip, mixed = run(["0"]), run(["1"]), run(["1", "0", "0", "1", "1"])
+    for i in range(3):
+        assert torch.equal(per_draw[i], on_chip[i]), i
+        assert torch.equal(per_draw[i], mixed[i]), i
+    assert float(per_draw[0][0].min()) == sum(steps // thin for steps, thin in launches)     # every chain counted every retained draw
