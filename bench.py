@@ -507,6 +507,29 @@ def time_config(gs, torch, name, n, S, seed=3521, ess=True, layout="auto", rng="
             "roofline_valu": roofline_valu(wl_key, d, tps, n, S, thin, s.mode, kern_ms, layout)}
 
 
+def host_api_rate(gs, torch, pdf, d, n, draws=100):
+    """PCIe-INCLUSIVE rate of the reference-shaped call (never `value`): `sampler.sample(draws)` returns every draw of every
+    chain as an ndarray (geosss/mcmc.py:55-77; scripts/curve_vMF.py:119-120 reads it on the host) -- page-locked memory, blocks of
+    chains copied under the next block's kernel (geosss_amd/mcmc.py _sample_to_host).  cold: the first call of its size (locks the
+    pages); warm: the previous array was dropped and its pages are reused."""
+    from geosss_amd import _pinned
+    x0 = gs.sample_sphere_device(d - 1, n, seed=0).T.contiguous()
+    out = {"call": f"sample({draws}) -> ndarray, {n} chains", "array_gb": 8e-9 * n * draws * d, "chain_steps": n * (draws - 1)}
+    _pinned.trim()
+    for label in ("cold", "warm"):
+        s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=3521)
+        s.advance(50)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        arr = s.sample(draws)
+        dt = time.perf_counter() - t0
+        out[label] = {"s": dt, "chain_steps_per_s": n * (draws - 1) / dt, "gb_per_s": arr.nbytes / dt / 1e9,
+                      "blocks": s._plan_blocks(0, draws, 1, None)}
+        del arr, s
+    _pinned.trim()
+    return out
+
+
 def time_sharded_config(gs, torch, dist, name, n, S, rank, world, barrier, gather_states, seed=3521, thin=100):
     """Another BASELINE config timed on EVERY rank of a multi-GPU run (cfg5: vMF mixture K = 10 kappa = 500, 10^6 chains per GPU,
     chain ids rank * 10^6 ..., final states gathered: SURVEY.md section 8(d)/(e); the reference's fan-out of independent
@@ -627,6 +650,10 @@ def compact_line(full, full_path=None):
         row.update(_pick(c, ["gather_ms", "ranks_seen"]))
         rows.append(row)
     out["configs"] = rows
+    if full.get("host_api"):  # PCIe-inclusive, never `value`: sample(100) -> ndarray end to end
+        h = full["host_api"]
+        out["host_api"] = {"chain_steps_per_s": h["warm"]["chain_steps_per_s"], "gb_per_s": h["warm"]["gb_per_s"],
+                           "cold_chain_steps_per_s": h["cold"]["chain_steps_per_s"]}
     if full_path:
         out["full_record"] = full_path
     line = json.dumps(_num(out), separators=(",", ":"))
@@ -834,6 +861,7 @@ def main(argv=None):
             out["configs"] = [time_config(gs, torch, name, nc, S, layout=args.layout) for name, nc in EXTRA_CONFIGS]
             out["configs"].append(time_config(gs, torch, *NUMPY_STREAM_CONFIG, S, layout=args.layout, rng="numpy"))
             out["configs"].append(time_config(gs, torch, *NUMPY_STREAM_CONFIG, S, layout=args.layout, screen=False, ess=False))
+            out["host_api"] = host_api_rate(gs, torch, pdf, d, n)
         if sharded is not None:
             out["configs"] = [sharded]
         if cpu is not None:
