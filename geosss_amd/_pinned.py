@@ -81,9 +81,26 @@ class _Block:
                 pass
 
 
+_warned = False
+
+
 def empty(shape, device=0):
     """A float64 ndarray of `shape` in page-locked host memory (C-contiguous).  Dropping the array (and its views) returns the
-    memory to the pool."""
+    memory to the pool.  Where the system refuses to lock that many pages (a memlock limit) the array is an ordinary one: the
+    copies into it are then staged by the driver -- slower, the same bytes."""
+    global _warned
     shape = tuple(int(v) for v in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(v) for v in shape)
     nbytes = 8 * int(np.prod(shape, dtype=np.int64)) if shape else 8
-    return _Block(nbytes, device).array(shape)
+    try:
+        return _Block(nbytes, device).array(shape)
+    except _lib.GsssError as e:
+        trim()                                   # cached blocks count against the same limit: give them back and try once more
+        try:
+            return _Block(nbytes, device).array(shape)
+        except _lib.GsssError:
+            if not _warned:
+                import warnings
+                warnings.warn(f"geosss_amd: {nbytes} bytes of page-locked host memory were refused ({e}); sample() returns a "
+                              "pageable array (the device-to-host copy runs at a fraction of the link's rate)", RuntimeWarning)
+                _warned = True
+            return np.empty(shape, dtype=np.float64)
