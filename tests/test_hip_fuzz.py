@@ -128,7 +128,7 @@ def test_group_kernel_slicing_does_not_change_a_bit(gs, case, monkeypatch):
     workgroup per chunk (GSSS_SLICE_STEPS=0), bitwise."""
     import torch
     rng = np.random.default_rng(7000 + case)
-    d = int(rng.choice([4, 5, 8, 10, 13, 16, 17, 24, 33, 50, 64, 65, 100, 128, 129, 200, 256]))
+    d = int(rng.choice([4, 5, 8, 10, 13, 16, 17, 24, 33, 49, 50, 52, 64, 65, 97, 100, 104, 128, 129, 193, 200, 208, 256]))   # (49 .. 52, 97 .. 104, 193 .. 208: the uneven layouts)
     k = int(rng.choice([2, 3, 7, 10, 10, 10, 12, 16 if d <= 64 else 17])) if d <= 48 or d > 64 else int(rng.choice([2, 5, 10, 10]))
     knots = gs.brownian_curve(k, d, 0.5, seed=int(rng.integers(1 << 30)))
     pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), float(rng.choice([100.0, 300.0, 800.0])))
