@@ -106,7 +106,7 @@ __host__ __device__ constexpr bool curvespec_parks_u()
 template <int L, int R>
 __host__ __device__ constexpr bool curvespec_parks_tail()
 {
-    return R > 0 && L < 16;
+    return R == 1 && L < 16;  // (two tail slots stay in registers everywhere: parked, <4, 3, 10, +2> is at the edge of three workgroups per CU)
 }
 template <int L, int Q, int NK, bool STATS>
 __host__ __device__ constexpr int curvespec_waves()
@@ -120,7 +120,7 @@ __host__ __device__ constexpr size_t curvespec_lds_doubles()
 {
     return (size_t)NK * (4 * Q * L + R * L) + 4 * (size_t)(NK - 1) + 2 * (size_t)(NK - 1) +
            (size_t)curvespec_scratch_doubles<L, NK>() * (kBlock / L) + kTabLds + 2 +
-           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)(4 * Q + (curvespec_parks_tail<L, R>() ? 1 : 0)) * kBlock : 0);
+           (curvespec_parks_u<Q, NK, HEAVY>() ? (size_t)(4 * Q + (curvespec_parks_tail<L, R>() ? R : 0)) * kBlock : 0);
 }
 
 // The all-double decision of one try (rare): threshold from x as the level of theta = 0 (mcmc.py:389, 397), FastCurve::level
@@ -182,16 +182,18 @@ __device__ __forceinline__ bool curvespec_decide_group(const FastCurve<1, NK> &s
     return scl.kappa * dot1 > scl.kappa * dot0 + fm::log_fast(u_thr);
 }
 
-// R = 1 (round 5): ONE more component per lane behind its Q quads -- the "uneven" layout for dimensions that miss a whole number
-// of quads per lane by a few components: d = 49 .. 52 as <4, 3, +1> (d = 50 is BASELINE cfg4), 97 .. 104 as <8, 3, +1>, 193 .. 208 as
-// <16, 3, +1> (d = 200 likewise).  The fourth quad cost those shapes the third wavefront per SIMD (254 / 246 registers, 15 % of the
-// SIMD cycles idle with nobody to switch to: VERDICT r4); 13 components a lane fit the three-quad register class.  Component
-// 4 Q L + g is lane g's tail slot; rows in LDS are [4 Q L main | L tail] doubles; its normal comes from Philox block 1 + Q L + g / 4
-// (the block of its quad, as in every other kernel: the stream does not know the layout).
+// R = 1, 2 (round 5): one or two more components per lane behind its Q quads -- the "uneven" layouts for dimensions that miss a
+// whole number of quads per lane by a few components (gsss_fast_curvespec.hip lists the shapes and what each gains): d = 50 as
+// <4, 3, +1> and d = 200 as <16, 3, +1> (BASELINE cfg4), d = 24 as <4, 1, +2>.  The next quad cost those shapes the register class
+// below (four quads: the third wavefront per SIMD -- 254 / 246 registers, 15 % of the SIMD cycles idle with nobody to switch to:
+// VERDICT r4).  Components 4 Q L + R g + r (r < R) are lane g's tail slots: scalars beside the register arrays of the quads; rows in
+// LDS are [4 Q L main | R L tail] doubles in component order; their normals come from Philox block 1 + Q L + R g / 4, word pair
+// (R g / 2) & 1 (the block of their quad, as in every other kernel: the stream does not know the layout).
 template <int L, int Q, int NK, bool REPLAY, bool STATS = false, int R = 0>
 __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) curvespec_kernel(TargetBlock tb, RunBlock a)
 {
-    static_assert(R == 0 || (R == 1 && !STATS && Q >= 2), "the tail slot: one component, plain and replay builds");
+    static_assert(R == 0 || ((R == 1 || R == 2) && !STATS), "tail slots: one or two components a lane, plain and replay builds");
+    constexpr int RS = R > 0 ? R : 1;            // (array extents)
     using V = CoopVec<L, 4 * Q>;
     using Scalar = FastCurve<1, NK>;  // its segment(): the double-precision restricted level
     constexpr int DMAIN = V::DPAD;               // components in the lanes' quads
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
     constexpr bool kParkU = curvespec_parks_u<Q, NK, REPLAY || STATS>();
     constexpr bool kParkT = kParkU && curvespec_parks_tail<L, R>();
     double2 *upark = reinterpret_cast<double2 *>(sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2) + threadIdx.x;
-    double *upark_t = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2 + (size_t)N * kBlock + threadIdx.x;  // (R: the tail slot's)
+    double *upark_t = sg + 6 * (size_t)(NK - 1) + (size_t)kScratch * (kBlock / L) + kTabLds + 2 + (size_t)N * kBlock + threadIdx.x;  // (R: tail slot r at [r * kBlock])
     Scalar sc;
     sc.knots = lds;
     sc.seg = sg;
@@ -289,8 +291,10 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
         const int cc = V::comp(g, i);
         x[i] = (cc < d) ? a.state[(size_t)cc * n + c] : 0.0;
     }
-    const int ct = DMAIN + g;            // (R) the component of this lane's tail slot
-    double xt = (R && ct < d) ? a.state[(size_t)ct * n + c] : 0.0;
+    const int ct = DMAIN + R * g;        // (R) the first component of this lane's tail slots: DMAIN + R g + r
+    double xt[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) xt[r] = (r < R && ct + r < d) ? a.state[(size_t)(ct + r) * n + c] : 0.0;
 
     PhiloxDraws<V> dr;
     dr.init(a, c, d);
@@ -342,7 +346,9 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
         c32s.seg32 = reinterpret_cast<const float4 *>(knots + (size_t)NK * DPAD + 4 * (NK - 1));
         // ---------------- draws of the step
         double u[N], u_thr, u_th0;
-        double ut = 0.0;  // (R) the tangent's tail slot
+        double ut[RS];  // (R) the tangent's tail slots
+#pragma unroll
+        for (int r = 0; r < RS; ++r) ut[r] = 0.0;
         int pref = 0;  // tries whose uniforms are in the ring: [.., pref)
         if (REPLAY) {
             const bool ok = cursor + d <= a.replay_stride;
@@ -351,7 +357,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 const int cc = V::comp(g, i);
                 u[i] = (cc < d) ? (ok ? rp[cursor + cc] : 0.5) : 0.0;
             }
-            if (R) ut = (ct < d) ? (ok ? rp[cursor + ct] : 0.5) : 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) ut[r] = (ct + r < d) ? (ok ? rp[cursor + ct + r] : 0.5) : 0.0;
             if (ok)
                 cursor += d;
             else {
@@ -392,18 +399,26 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             }
             pref = 4 * (L * Q - nq - 1);
             if (R) {
-                // the tail round: lane g < T draws the block of its tail component's quad (4 Q L + g is word pair (g & 2) of block
-                // 1 + Q L + g / 4: ONE Box-Muller pair, the half of it this lane keeps); lanes past the tail draw block 0 and the
-                // first tries' blocks, as the lanes past the normals do in the even layouts
-                const int T = d - DMAIN;  // 1 .. L tail components (the host picks this build for no other d)
-                const int e = g - T;
+                // the tail round: a lane that holds tail components draws the block of their quad -- components DMAIN + R g + r sit in
+                // word pair (R g / 2) & 1 of block 1 + Q L + R g / 4: ONE Box-Muller pair, of which the lane keeps one half (R = 1) or
+                // both (R = 2); lanes past the tail draw block 0 and the first tries' blocks, as the lanes past the normals do in the
+                // even layouts
+                const int T = d - DMAIN;              // 1 .. R L tail components (the host picks this build for no other d)
+                const int tl = (T + R - 1) / R;       // lanes that hold some
+                const int e = g - tl;
                 uint32_t w[4];
-                dr.words(e < 0 ? 1u + (uint32_t)(Q * L + (g >> 2)) : (e == 0 ? 0u : try_base + (uint32_t)(e - 1)), w);
+                dr.words(e < 0 ? 1u + (uint32_t)(Q * L + ((R * g) >> 2)) : (e == 0 ? 0u : try_base + (uint32_t)(e - 1)), w);
+                const bool second_pair = (((R * g) >> 1) & 1) != 0;
                 double za, zb;
-                box_muller32((g & 2) ? w[2] : w[0], (g & 2) ? w[3] : w[1], tab, za, zb);
-                ut = e < 0 ? ((g & 1) ? zb : za) : 0.0;
+                box_muller32(second_pair ? w[2] : w[0], second_pair ? w[3] : w[1], tab, za, zb);
+                if (R == 1) {
+                    ut[0] = (e < 0 && ct < d) ? ((g & 1) ? zb : za) : 0.0;
+                } else {
+                    ut[0] = (e < 0 && ct < d) ? za : 0.0;
+                    ut[RS - 1] = (e < 0 && ct + 1 < d) ? zb : 0.0;
+                }
                 publish_extra(e, w);
-                pref = 4 * (L - T - 1);
+                pref = 4 * (L - tl - 1);
             }
             if (pref < 0) {  // every lane holds normals: block 0 and the first tries take a round of their own
                 uint32_t w[4];
@@ -414,11 +429,12 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             u_thr = u_th0 = 0.0;  // (published to the group's LDS words: read behind the wave_sync that follows the knot dots)
         }
         // ---------------- u = spherical_projection(z, x)   (sphere.py:29-33)
-        auto gdot = [&](const double (&p)[N], double pt, const double (&r)[N], double rt) -> double {  // (R = 0: vdot<V>, its bits)
+        auto gdot = [&](const double (&p)[N], const double (&pt)[RS], const double (&q)[N], const double (&qt)[RS]) -> double {  // (R = 0: vdot<V>, its bits)
             double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc = fma(p[i], r[i], acc);
-            if (R) acc = fma(pt, rt, acc);
+            for (int i = 0; i < N; ++i) acc = fma(p[i], q[i], acc);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc = fma(pt[r], qt[r], acc);
             return group_sum<L>(acc);
         };
         const double xx = gdot(x, xt, x, xt);
@@ -426,7 +442,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
         const double cz = gdot(u, ut, x, xt) * rnx;
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] = fma(-cz * rnx, x[i], u[i]);  // w = z - (z . n) n
-        if (R) ut = fma(-cz * rnx, xt, ut);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ut[r] = fma(-cz * rnx, xt[r], ut[r]);
         // ---------------- a_r . u = (a_r . w) / |w|, a_r . x; single-precision pack; the doubles parked for decide()
         const bool refresh = !kRecur || s == 0 || ((step0 + (uint64_t)s) % kCoefRefresh) == 0;
         float q[Curve32<NK, (L < GSSS_CS_PACKED_BELOW)>::kFloats];
@@ -434,7 +451,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             double pw = 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) pw = fma(u[i], u[i], pw);
-            if (R) pw = fma(ut, ut, pw);
+#pragma unroll
+            for (int r = 0; r < R; ++r) pw = fma(ut[r], ut[r], pw);
             const double rnw = inv_norm(group_sum<L>(pw));
             // Round 4: the knot rows software-pipelined -- row r + 1 is read from LDS while row r is multiplied (N more registers, the
             // same products in the same order, the same bits).  The two-wavefront builds wait on LDS with nobody to switch to (vector
@@ -459,11 +477,19 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 };
                 double2 cur_row[N / 2], nxt_row[N / 2];
                 load_part(0, cur_row, 0, N / 2);
-                double cur_t = R ? knots[DMAIN + g] : 0.0, nxt_t = 0.0;  // (R) the rows' tail slots, one row ahead like the rest
+                double cur_t[RS], nxt_t[RS];  // (R) the rows' tail slots, one row ahead like the rest
+#pragma unroll
+                for (int r = 0; r < RS; ++r) {
+                    cur_t[r] = r < R ? knots[ct + r] : 0.0;
+                    nxt_t[r] = 0.0;
+                }
 #pragma unroll
                 for (int r = 0; r < NK; ++r) {
                     if (r + 1 < NK) load_part(r + 1, nxt_row, 0, kAhead);
-                    if (R && r + 1 < NK) nxt_t = knots[(size_t)(r + 1) * DPAD + DMAIN + g];
+                    if (R && r + 1 < NK) {
+#pragma unroll
+                        for (int t = 0; t < R; ++t) nxt_t[t] = knots[(size_t)(r + 1) * DPAD + ct + t];
+                    }
                     double pu = 0.0, px = 0.0;
 #pragma unroll
                     for (int i = 0; i < N; i += 2) {
@@ -473,10 +499,11 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                         pu = fma(kv.y, u[i + 1], pu);
                         if (refresh) px = fma(kv.y, x[i + 1], px);
                     }
-                    if (R) {
-                        pu = fma(cur_t, ut, pu);
-                        if (refresh) px = fma(cur_t, xt, px);
-                        cur_t = nxt_t;
+#pragma unroll
+                    for (int t = 0; t < R; ++t) {
+                        pu = fma(cur_t[t], ut[t], pu);
+                        if (refresh) px = fma(cur_t[t], xt[t], px);
+                        cur_t[t] = nxt_t[t];
                     }
                     const double au = group_sum<L>(pu) * rnw;
                     const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
@@ -518,10 +545,11 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                             if (refresh) px = fma(kv.y, x[i + 1], px);
                         }
                     }
-                    if (R) {  // the row's tail slot
-                        const double kt = row[DMAIN + g];
-                        pu = fma(kt, ut, pu);
-                        if (refresh) px = fma(kt, xt, px);
+#pragma unroll
+                    for (int t = 0; t < R; ++t) {  // the row's tail slots
+                        const double kt = row[ct + t];
+                        pu = fma(kt, ut[t], pu);
+                        if (refresh) px = fma(kt, xt[t], px);
                     }
                     const double au = group_sum<L>(pu) * rnw;
                     const double axr = refresh ? group_sum<L>(px) : coef[2 * r];
@@ -544,9 +572,10 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                 u[i + 1] *= rnw;
                 if (kParkU) upark[(size_t)(i / 2) * kBlock] = make_double2(u[i], u[i + 1]);
             }
-            if (R) {
-                ut *= rnw;
-                if (kParkT) upark_t[0] = ut;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                ut[r] *= rnw;
+                if (kParkT) upark_t[(size_t)r * kBlock] = ut[r];
             }
         }
         wave_sync();  // (one synchronisation for the step's uniforms, the parked coefficients and u)
@@ -615,8 +644,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             if (shrink) {  // (two loops: the sampler is the same for the whole launch, a select per end and try otherwise)
 #pragma unroll
                 for (int qq = 0; qq < L; ++qq) {
-                    const double ut = REPLAY ? ring[qq] : try_uniform(ring32[(t_base + qq) & (kRing32 - 1)]);
-                    const double theta = fma(hi - lo, ut, lo);  // mcmc.py:395
+                    const double u_try = REPLAY ? ring[qq] : try_uniform(ring32[(t_base + qq) & (kRing32 - 1)]);
+                    const double theta = fma(hi - lo, u_try, lo);  // mcmc.py:395
                     if (g == qq) my_theta = theta;
                     const bool neg = theta < 0.0;               // mcmc.py:400, assuming try qq is rejected
                     lo = neg ? theta : lo;
@@ -625,8 +654,8 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             } else {
 #pragma unroll
                 for (int qq = 0; qq < L; ++qq) {
-                    const double ut = REPLAY ? ring[qq] : try_uniform(ring32[(t_base + qq) & (kRing32 - 1)]);
-                    const double theta = fma(hi - lo, ut, lo);  // mcmc.py:367, 395: the bracket stays (0, 2 pi)
+                    const double u_try = REPLAY ? ring[qq] : try_uniform(ring32[(t_base + qq) & (kRing32 - 1)]);
+                    const double theta = fma(hi - lo, u_try, lo);  // mcmc.py:367, 395: the bracket stays (0, 2 pi)
                     if (g == qq) my_theta = theta;
                 }
             }
@@ -693,11 +722,13 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                     x[i] = fma(sn, up.x, cs * x[i]);
                     x[i + 1] = fma(sn, up.y, cs * x[i + 1]);
                 }
-                if (R) xt = fma(sn, kParkT ? upark_t[0] : ut, cs * xt);
+#pragma unroll
+                for (int r = 0; r < R; ++r) xt[r] = fma(sn, kParkT ? upark_t[(size_t)r * kBlock] : ut[r], cs * xt[r]);
             } else {
 #pragma unroll
                 for (int i = 0; i < N; ++i) x[i] = fma(sn, u[i], cs * x[i]);
-                if (R) xt = fma(sn, ut, cs * xt);
+#pragma unroll
+                for (int r = 0; r < R; ++r) xt[r] = fma(sn, ut[r], cs * xt[r]);
             }
             if (kRecur && g == 0) {
 #pragma unroll
@@ -712,7 +743,9 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
                         const int cc = V::comp(g, i);
                         if (cc < d) a.samples[sample_index(a, row_out, cc, d, c)] = x[i];
                     }
-                    if (R && ct < d) a.samples[sample_index(a, row_out, ct, d, c)] = xt;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (ct + r < d) a.samples[sample_index(a, row_out, ct + r, d, c)] = xt[r];
                 }
                 if constexpr (STATS) stats_update_group<V>(a, c, g, d, x);  // (`alive` is the same in every lane of a group)
                 ++row_out;
@@ -727,7 +760,9 @@ __global__ void __launch_bounds__(kBlock, (curvespec_waves<L, Q, NK, STATS>())) 
             const int cc = V::comp(g, i);
             if (cc < d) a.state[(size_t)cc * n + c] = x[i];
         }
-        if (R && ct < d) a.state[(size_t)ct * n + c] = xt;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (ct + r < d) a.state[(size_t)(ct + r) * n + c] = xt[r];
         if (g == 0) {
             if (a.n_reject) a.n_reject[c] += n_try - steps_done;
             if (a.n_tries) a.n_tries[c] += n_try;

@@ -32,27 +32,38 @@ int launch_curvespec(const TargetBlock &tb, const RunBlock &rb, bool replay, Fas
             return do_curvespec<2, 2, 10>(tb, rb, replay, st);
         }
     }
-    // Round 5: dimensions that miss a whole number of quads per lane by at most one component per lane run the UNEVEN layout --
-    // Q = 3 quads and one tail slot per lane (gsss_curvespec.h, R = 1) -- in the three-wavefront register class of the three-quad
-    // builds instead of four quads at two wavefronts.  Measured, ms per 10^8 chain-steps (profiles/r05_ab_curve_tail.log):
-    //   d = 49 .. 52   <4, 3, 10, +1>   d = 50 (BASELINE cfg4): 32.50 -> 27.23 (+19 %)
-    //   d = 97 .. 104  <8, 3, 10, +1>   d = 100: 52.15 -> 44.01 (+18 %)
-    //   d = 193 .. 208 <16, 3, 10, +1>  d = 200 (cfg4): 94.03 -> 80.45 (+17 %) -- with the tail slot of the tangent kept in a register:
-    //                                   parked in LDS like the quads' the workgroup needs 55.8 KB, two workgroups per CU under a
-    //                                   kernel built for three wavefronts per SIMD: 106.7 ms
-    // GSSS_CURVE_TAIL=0 turns the layout off (A/B).  Plain and replayed launches of curves of <= 10 knots; statistics builds keep
+    // Round 5: dimensions that miss a whole number of quads per lane by at most two components per lane run an UNEVEN layout -- Q
+    // quads and R = 1 or 2 tail slots per lane (gsss_curvespec.h) -- in the register class of the Q-quad build instead of the
+    // (Q + 1)-quad one (four quads: two wavefronts per SIMD instead of three).  Measured, ms per 10^8 chain-steps against the even
+    // layout (profiles/r05_ab_curve_tail.log):
+    //   <4, 1, 10, +1>  d = 17 .. 20    d = 18: 20.84 -> 19.53 (+6.7 %)      <4, 1, 10, +2>  d = 21 .. 24    d = 24 (bench): 20.74 -> 20.05 (+3.4 %)
+    //   <4, 2, 10, +1>  d = 33 .. 36    d = 34: 23.80 -> 22.20 (+7.2 %)      <4, 2, 10, +2>  d = 37 .. 40    d = 38: 24.05 -> 23.12 (+4.0 %)
+    //   <4, 3, 10, +1>  d = 49 .. 52    d = 50 (BASELINE cfg4): 31.40 -> 25.29 (+24 %)
+    //   <4, 3, 10, +2>  d = 53 .. 56    d = 54: 31.47 -> 26.47 (+19 %) -- two tail slots stay in registers: parked in LDS the workgroup is
+    //                                   54.1 KB and the CU holds two of them (32.2 ms)
+    //   <8, 3, 10, +1>  d = 97 .. 104   d = 100: 52.07 -> 43.64 (+19 %)      <8, 3, 10, +2>  d = 105 .. 112  d = 108: 52.43 -> 45.06 (+16 %)
+    //   <16, 3, 10, +1> d = 193 .. 208  d = 200 (cfg4): 93.78 -> 74.45 (+26 %) -- its ONE tail slot in a register for the same reason
+    //   (<16, 3, 10, +2>, d = 209 .. 224: 55 KB of LDS whatever is parked, two workgroups per CU: 93.9 -> 98.8 ms; not built)
+    // GSSS_CURVE_TAIL=0 turns the layouts off (A/B).  Plain and replayed launches of curves of <= 10 knots; statistics builds keep
     // the even layouts.
     if (tb.k <= 10 && (probe || rb.stats == nullptr)) {
         const char *env_tail = getenv("GSSS_CURVE_TAIL");  // (read per launch: tests switch it)
         const int tail = env_tail ? atoi(env_tail) : 1;
-#define GSSS_SPEC_TAIL(LL)                                                                     \
+#define GSSS_SPEC_TAIL(LL, QQ, RR)                                                             \
     do {                                                                                       \
-        if (probe) GSSS_PROBE(lane, "curvespec_kernel<%d, 3, 10, +1>", LL);                    \
-        return do_curvespec<LL, 3, 10, 1>(tb, rb, replay, st);                                 \
+        if (probe) GSSS_PROBE(lane, "curvespec_kernel<%d, %d, 10, +%d>", LL, QQ, RR);          \
+        return do_curvespec<LL, QQ, 10, RR>(tb, rb, replay, st);                               \
     } while (0)
-        if (tail >= 1 && tb.d > 48 && tb.d <= 52) GSSS_SPEC_TAIL(4);
-        if (tail >= 1 && tb.d > 96 && tb.d <= 104) GSSS_SPEC_TAIL(8);
-        if (tail >= 1 && tb.d > 192 && tb.d <= 208) GSSS_SPEC_TAIL(16);
+        // <L, Q, +R> holds 4 Q L + R L components: four-lane groups at d <= 64, eight at 65 .. 128, sixteen beyond
+        if (tail >= 1 && tb.d > 16 && tb.d <= 20) GSSS_SPEC_TAIL(4, 1, 1);
+        if (tail >= 1 && tb.d > 20 && tb.d <= 24) GSSS_SPEC_TAIL(4, 1, 2);
+        if (tail >= 1 && tb.d > 32 && tb.d <= 36) GSSS_SPEC_TAIL(4, 2, 1);
+        if (tail >= 1 && tb.d > 36 && tb.d <= 40) GSSS_SPEC_TAIL(4, 2, 2);
+        if (tail >= 1 && tb.d > 48 && tb.d <= 52) GSSS_SPEC_TAIL(4, 3, 1);
+        if (tail >= 1 && tb.d > 52 && tb.d <= 56) GSSS_SPEC_TAIL(4, 3, 2);
+        if (tail >= 1 && tb.d > 96 && tb.d <= 104) GSSS_SPEC_TAIL(8, 3, 1);
+        if (tail >= 1 && tb.d > 104 && tb.d <= 112) GSSS_SPEC_TAIL(8, 3, 2);
+        if (tail >= 1 && tb.d > 192 && tb.d <= 208) GSSS_SPEC_TAIL(16, 3, 1);
 #undef GSSS_SPEC_TAIL
     }
     if (tb.d <= 16) GSSS_SPEC(4, 1);

@@ -219,7 +219,10 @@ def test_group_kernels_do_not_spill():
             "ILi4ELi1ELi17ELb0ELb0ELi0E": 3, "ILi4ELi2ELi17ELb0ELb0ELi0E": 3, "ILi16ELi1ELi17ELb0ELb0ELi0E": 3, "ILi16ELi2ELi17ELb0ELb0ELi0E": 3,
             "ILi4ELi4ELi10ELb0ELb0ELi0E": 2, "ILi8ELi4ELi10ELb0ELb0ELi0E": 2, "ILi16ELi4ELi10ELb0ELb0ELi0E": 2,
             # round 5: three quads + one tail component per lane (d = 49 .. 52, 97 .. 104, 193 .. 208; cfg4's d = 50 / 200)
-            "ILi4ELi3ELi10ELb0ELb0ELi1E": 3, "ILi8ELi3ELi10ELb0ELb0ELi1E": 3, "ILi16ELi3ELi10ELb0ELb0ELi1E": 3}  # <L, Q, NK, replay, stats, tail> -> waves per SIMD
+            "ILi4ELi3ELi10ELb0ELb0ELi1E": 3, "ILi8ELi3ELi10ELb0ELb0ELi1E": 3, "ILi16ELi3ELi10ELb0ELb0ELi1E": 3,
+            # ... one behind one and two quads, and two tail components per lane (d = 17 .. 24 -- cfg4's overlap point d = 24 --, 33 .. 40, 53 .. 56, 105 .. 112)
+            "ILi4ELi1ELi10ELb0ELb0ELi1E": 3, "ILi4ELi1ELi10ELb0ELb0ELi2E": 3, "ILi4ELi2ELi10ELb0ELb0ELi1E": 3, "ILi4ELi2ELi10ELb0ELb0ELi2E": 3,
+            "ILi4ELi3ELi10ELb0ELb0ELi2E": 3, "ILi8ELi3ELi10ELb0ELb0ELi2E": 3}  # <L, Q, NK, replay, stats, tail> -> waves per SIMD
     # scratch a build may hold (bytes a lane).  Two and three component quads per lane are the MEASURED exceptions to "no
     # scratch": three wavefronts with 128 .. 224 bytes spilled are 16-22 % faster than two without (gsss_curvespec.h,
     # profiles/r04_ab_q2_three_waves.log; the resident wavefronts' scratch stays in or near the L2), which four quads are not
@@ -228,9 +231,11 @@ def test_group_kernels_do_not_spill():
               "ILi8ELi3ELi10ELb0ELb0ELi0E": 116, "ILi16ELi3ELi10ELb0ELb0ELi0E": 108,
               "ILi4ELi1ELi17ELb0ELb0ELi0E": 160, "ILi4ELi2ELi17ELb0ELb0ELi0E": 184, "ILi16ELi1ELi17ELb0ELb0ELi0E": 152, "ILi16ELi2ELi17ELb0ELb0ELi0E": 180,
               # (round 5: the try uniforms rest in LDS as 32-bit words -- every build lost 12 .. 48 B of scratch; the three-quad builds run
-              # without the knot-row pipeline: 176 / 140 / 184 -> 124 / 116 / 108 B, the uneven ones 216 / 184 / 240 -> 168 / 168 / 160 B, so that
+              # without the knot-row pipeline: 176 / 140 / 184 -> 124 / 116 / 108 B, the uneven ones 216 / 184 / 240 -> 176 / 168 / 160 B, so that
               # the resident wavefronts' scratch stays under an XCD's 4 MB of L2: profiles/r05_ab_knot_pipe_q3.log)
-              "ILi4ELi3ELi10ELb0ELb0ELi1E": 168, "ILi8ELi3ELi10ELb0ELb0ELi1E": 168, "ILi16ELi3ELi10ELb0ELb0ELi1E": 160}
+              "ILi4ELi3ELi10ELb0ELb0ELi1E": 176, "ILi8ELi3ELi10ELb0ELb0ELi1E": 168, "ILi16ELi3ELi10ELb0ELb0ELi1E": 160,
+              "ILi4ELi1ELi10ELb0ELb0ELi1E": 56, "ILi4ELi1ELi10ELb0ELb0ELi2E": 64, "ILi4ELi2ELi10ELb0ELb0ELi1E": 160, "ILi4ELi2ELi10ELb0ELb0ELi2E": 188,
+              "ILi4ELi3ELi10ELb0ELb0ELi2E": 212, "ILi8ELi3ELi10ELb0ELb0ELi2E": 196}
     seen = 0
     for name, r in ru.items():
         for key, waves in want.items():

@@ -127,7 +127,7 @@ def test_curve_d50_launch_matches_oracle(gs, oracle, monkeypatch):
     assert n_checked == 480
 
 
-@pytest.mark.parametrize("workload,kernel,per,m,per_cu", [("curve_d10", "curvespec_kernel<4, 1, 10", 64, 320, 3), ("curve_d24", "curvespec_kernel<4, 2, 10", 64, 200, 3),
+@pytest.mark.parametrize("workload,kernel,per,m,per_cu", [("curve_d10", "curvespec_kernel<4, 1, 10", 64, 320, 3), ("curve_d24", "curvespec_kernel<4, 1, 10, +2>", 64, 200, 3),
                                                            ("curve_d200", "curvespec_kernel<16, 3, 10, +1>", 16, 48, 3)])
 def test_curve_launches_match_oracle(gs, oracle, monkeypatch, workload, kernel, per, m, per_cu):
     """cfg4's other points at their full size (10^5 chains x 1000 transitions, every chunk sliced): three- and two-wavefront builds,

@@ -397,6 +397,9 @@ SYNTH = [("vmf", 11, 6), ("vmf", 13, 4), ("vmf", 14, 2), ("vmf", 12, 7), ("vmf",
          # eight-lane groups, 193 .. 208 in sixteen-lane groups -- one tail component, a full tail (every lane's slot taken: block 0 and the tries get a round of their own)
          ("curve", 49, 10), ("curve", 51, 7), ("curve", 52, 10), ("curve", 97, 10), ("curve", 101, 3), ("curve", 104, 10),
          ("curve", 200, 10), ("curve", 205, 4), ("curve", 208, 10),   # (193: above, with the layout boundaries)
+         # ... and two tail components per lane (d = 21 .. 24 in <4, 1, +2>, ...), one behind one and two quads (d = 17 .. 20, 33 .. 36)
+         ("curve", 18, 10), ("curve", 20, 4), ("curve", 22, 10), ("curve", 23, 7), ("curve", 34, 10), ("curve", 36, 3), ("curve", 37, 10),
+         ("curve", 39, 5), ("curve", 53, 10), ("curve", 56, 10), ("curve", 105, 10), ("curve", 111, 6), ("curve", 209, 10),
          # cooperative mixture kernels: slots per lane 4 | 8 | 16 at d = 64 | 65, 128 | 129; up to 256
          ("vmf", 64, 3), ("vmf", 65, 5), ("vmf", 128, 3), ("vmf", 129, 2), ("vmf", 256, 16)]
 
@@ -445,17 +448,20 @@ def test_synthetic_shapes_match_oracle(gs, oracle, kind, d, k, monkeypatch):
     assert np.max(np.abs(lp - ref) / np.maximum(1, np.abs(ref))) < TOL
 
 
-@pytest.mark.parametrize("d,k,even", [(50, 10, "curvespec_kernel<4, 4, 10"), (100, 7, "curvespec_kernel<8, 4, 10"), (200, 10, "curvespec_kernel<16, 4, 10")])
+@pytest.mark.parametrize("d,k,even", [(18, 10, "curvespec_kernel<4, 2, 10"), (24, 10, "curvespec_kernel<4, 2, 10"), (36, 7, "curvespec_kernel<4, 3, 10"),
+                                      (50, 10, "curvespec_kernel<4, 4, 10"), (55, 10, "curvespec_kernel<4, 4, 10"), (100, 7, "curvespec_kernel<8, 4, 10"),
+                                      (110, 10, "curvespec_kernel<8, 4, 10"), (200, 10, "curvespec_kernel<16, 4, 10")])
 def test_even_layouts_behind_the_switch_match_oracle(gs, oracle, d, k, even, monkeypatch):
     """GSSS_CURVE_TAIL=0: the four-quad builds the uneven layouts replaced at d = 49 .. 52, 97 .. 104, 193 .. 208 are still what
-    statistics launches of those dimensions run, and what the A/B of profiles/r05_ab_curve_tail.log timed: held to the oracle too."""
+    statistics launches of those dimensions run, and what the A/B of profiles/r05_ab_curve_tail.log timed: held to the oracle too
+    (the uneven layouts by now also cover d = 17 .. 24, 33 .. 40, 53 .. 56 and 105 .. 112)."""
     knots = gs.brownian_curve(k, d, 0.5, seed=d)
     pdf = gs.CurvedVonMisesFisher(gs.SlerpCurve(knots), 300.0)
     tgt = oracle.Target.curve_vmf(knots, 300.0)
     n_chains, n_steps = 70, 12
     x0 = oracle.sample_sphere(3, n_chains, d)
     want = oracle.run(tgt, x0, n_steps, seed=77, n_threads=8)
-    assert _packed_kernel(gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement="packed")).endswith("3, 10, +1>")
+    assert _packed_kernel(gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement="packed")).endswith((", 10, +1>", ", 10, +2>"))
     monkeypatch.setenv("GSSS_CURVE_TAIL", "0")
     s = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=77, placement="packed")
     assert _packed_kernel(s).startswith(even)
