@@ -46,6 +46,7 @@ _MAX_STEPS_PER_LAUNCH = 4096
 # sample() -> ndarray: below this many bytes the array is copied in one piece; above, blocks of chains are sampled and copied in a
 # pipeline (the copy of block k under the kernel of block k + 1)
 _PIPELINE_MIN_BYTES = 64 << 20
+_PINNED_MIN_BYTES = 1 << 20   # below: an ordinary (pageable) array
 _COPY_GBS = 45.0          # what a device-to-host copy into page-locked memory sustains (planning figure for the number of blocks)
 _ROUND_STEP_S = 16e-6     # one transition of one resident round of workgroups (README mixture: 15 us; planning figure)
 
@@ -599,6 +600,11 @@ class RejectionSphericalSliceSampler:
     def _sample_to_host(self, skip, n_rows, thin, blocks):
         n, d = self.n_chains, self.d
         blocks = self._plan_blocks(skip, n_rows, thin, blocks)
+        if 8 * n * n_rows * d < _PINNED_MIN_BYTES and blocks == 1:
+            # a small array (one chain's README call: 24 KB): locking pages would cost more than the staged copy of a pageable one
+            out = torch.empty((n, n_rows, d), dtype=torch.float64, device=self._tdev)
+            self._sample_rows(out, skip, n_rows, thin)
+            return out.cpu().numpy()
         host = _pinned.empty((n, n_rows, d), self.device)
         lib, dev = self._lib, self.device
         main = torch.cuda.current_stream(dev)
