@@ -586,7 +586,7 @@ def time_sharded_config(gs, torch, dist, name, n, S, rank, world, barrier, gathe
 def _num(v, digits=6):
     """Floats of the printed line at 6 significant digits (the full record keeps every digit)."""
     if isinstance(v, float):
-        return float(f"{v:.{digits}g}")
+        return float(f"{v:.{digits}g}") if v == v and abs(v) != float("inf") else None   # (strict JSON: no NaN / Infinity in the line)
     if isinstance(v, dict):
         return {k: _num(x, digits) for k, x in v.items()}
     if isinstance(v, (list, tuple)):
