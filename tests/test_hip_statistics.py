@@ -264,9 +264,13 @@ def test_running_statistics_equal_stored_draw_diagnostics(gs, name, mode, placem
 
 @pytest.mark.parametrize("name,resident", [("vmfmix_readme", 1024), ("bingham_d10_vmax30", 512)])
 @pytest.mark.parametrize("per_lane", [2, 1])
-def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, per_lane, monkeypatch):
+@pytest.mark.parametrize("onchip", ["1", "0"])
+def test_running_statistics_of_a_sliced_partial_round(gs, name, resident, per_lane, onchip, monkeypatch):
     """The statistics build of the lane kernels slices its last partial round like the plain build (plan_partial_round) and
-    hands the accumulators from slice to slice with plain stores behind an agent-scope release: the same bits as unsliced."""
+    hands the accumulators from slice to slice with plain stores behind an agent-scope release: the same bits as unsliced.
+    (onchip "1": round 5's default, a slice's working set in registers and LDS, one chain per lane whatever the packing asked
+    for; "0": the per-draw rows in HBM of rounds 2-4, with either packing.)"""
+    monkeypatch.setenv("GSSS_STATS_ONCHIP", onchip)
     import ctypes as C
     import torch
     from conftest import golden
