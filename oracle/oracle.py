@@ -85,7 +85,9 @@ class Target:
         w = np.ones(k) if weights is None else np.array(weights, dtype=float)
         w = w / w.sum()                                            # distributions.py:213-216
         lognorm = np.log(2 * np.pi) + log_i0(np.linalg.norm(mu, axis=1))  # distributions.py:157
-        return cls(VMF_MIXTURE, d, k, mu=mu, lognorm=lognorm, logw=np.log(w))
+        with np.errstate(divide="ignore"):                          # (a zero weight is log 0 = -inf on purpose, as in the reference)
+            logw = np.log(w)
+        return cls(VMF_MIXTURE, d, k, mu=mu, lognorm=lognorm, logw=logw)
 
     @classmethod
     def bingham(cls, A, b=None):
