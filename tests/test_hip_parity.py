@@ -263,6 +263,26 @@ def test_sample_in_blocks_equals_one_launch(gs, name, rng, n, kw):
     assert np.array_equal(runs[1][1][:, 0], runs[1][0][:, -1])      # row 0 of the second call = last row of the first
 
 
+def test_sample_falls_back_to_a_pageable_array_when_pages_cannot_be_locked(gs, monkeypatch):
+    """Where the system refuses to page-lock the array (a memlock limit), `sample()` still returns the reference's ndarray
+    (mcmc.py:55-77) -- an ordinary one, the same values, with one warning -- rather than failing: the return path degrades, the
+    sampling itself has no fallback."""
+    from geosss_amd import _lib, _pinned
+    z = golden("traj_vmfmix_readme.npz")
+    pdf = product_target(z)
+    x0 = gs.sample_sphere_device(2, 60_000, seed=3).T
+    want = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=5).sample(12, blocks=3)
+
+    def refuse(self, nbytes, device):
+        raise _lib.GsssError("gsss: hipHostMalloc refused (test)")
+
+    monkeypatch.setattr(_pinned._Block, "__init__", refuse)
+    monkeypatch.setattr(_pinned, "_warned", False)
+    with pytest.warns(RuntimeWarning, match="page-locked host memory were refused"):
+        got = gs.ShrinkageSphericalSliceSampler(pdf, x0, seed=5).sample(12, blocks=3)
+    assert isinstance(got, np.ndarray) and got.base is None and np.array_equal(got, want)
+
+
 def test_sample_plans_blocks_for_a_large_array(gs, monkeypatch):
     """400 000 README chains x 40 rows (384 MB): the default plan pipelines it in several blocks, the array is the one-block
     array; samplers with further per-chain launch state (RWMH) and running statistics stay in one launch sequence; page-locked
