@@ -74,6 +74,8 @@ SIGNATURES = {
     "gsss_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "gsss_malloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),
     "gsss_free_host": (C.c_int, [C.c_void_p]),
+    "gsss_host_register": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
+    "gsss_host_unregister": (C.c_int, [C.c_void_p]),
     "gsss_memcpy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "gsss_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),
     "gsss_stream_synchronize": (C.c_int, [C.c_int, C.c_void_p]),

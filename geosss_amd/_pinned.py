@@ -2,10 +2,14 @@
 
 The reference's `Sampler.sample` returns an ndarray (geosss/mcmc.py:55-77) and every script reads it on the host
 (scripts/curve_vMF.py:119-120).  At 10^6 chains that array is gigabytes; a device-to-host copy into ordinary (pageable) memory
-is staged by the driver at ~9 GB/s, a sixth of the PCIe link.  So the returned array LIVES in page-locked memory
-(`gsss_malloc_host`): the device writes into it directly, block of chains by block of chains, while the next block is being
-sampled.  Locking pages costs about as much as touching them for the first time, so blocks go back to a small pool when the array
-(and every view of it) is dropped and the next `sample()` of the same size reuses them.
+is staged by the driver at ~11 GB/s, a fifth of the PCIe link.  So the returned array LIVES in page-locked memory: the device
+writes into it directly, block of chains by block of chains, while the next block is being sampled.
+
+Locking pages is cheap (4 ms for 2.4 GB) -- what costs is FAULTING them in, which `hipHostMalloc` / `hipHostRegister` do one page
+after the other inside the call (105 ms).  So the memory is an ordinary numpy allocation whose pages are touched from several
+threads first (11 ms on 16 threads) and locked where they lie (`gsss_host_register`; tools/microbench_pinning.py has the
+measurements).  Blocks go back to a small pool when the array (and every view of it) is dropped, and the next `sample()` of the
+same size reuses them with nothing to fault or lock.
 """
 import ctypes as C
 import os
@@ -17,66 +21,104 @@ from . import _lib
 
 # cached (free) bytes the pool may hold before it gives blocks back to the system
 POOL_BYTES = int(os.environ.get("GSSS_PINNED_POOL_BYTES", str(8 << 30)))
+_PAGE = 4096
 _lock = threading.Lock()
-_free = []  # [(bytes, address)]
+_free = []  # [_Memory]
+
+
+def _threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(16, n))
+
+
+class _Memory:
+    """One page-locked region: a numpy byte buffer (which owns the pages) registered with the device from its first page boundary."""
+
+    def __init__(self, nbytes, device):
+        size = (max(1, nbytes) + _PAGE - 1) // _PAGE * _PAGE
+        self.buf = np.empty(size + _PAGE, dtype=np.uint8)
+        self.addr = (self.buf.ctypes.data + _PAGE - 1) // _PAGE * _PAGE
+        self.size = size
+        off = self.addr - self.buf.ctypes.data
+        view = self.buf[off: off + size]
+        k = _threads() if size >= (64 << 20) else 1
+
+        def touch(i):                       # one write per page: the fault is the cost (numpy releases the GIL for the strided store)
+            view[i * size // k: (i + 1) * size // k: _PAGE] = 0
+
+        if k == 1:
+            touch(0)
+        else:
+            workers = [threading.Thread(target=touch, args=(i,)) for i in range(k)]
+            for w in workers:
+                w.start()
+            for w in workers:
+                w.join()
+        _lib.check(_lib.load().gsss_host_register(C.c_void_p(self.addr), size, device))
+        self.registered = True
+
+    def release(self):
+        if getattr(self, "registered", False):
+            self.registered = False
+            try:
+                _lib.load().gsss_host_unregister(C.c_void_p(self.addr))
+            except Exception:  # interpreter shutdown
+                pass
+        self.buf = None
+
+    def __del__(self):
+        self.release()
 
 
 def _take(nbytes):
     with _lock:
         best = None
-        for i, (size, _) in enumerate(_free):
-            if nbytes <= size <= nbytes + (nbytes >> 2) + (1 << 20) and (best is None or size < _free[best][0]):
+        for i, m in enumerate(_free):
+            if nbytes <= m.size <= nbytes + (nbytes >> 2) + (1 << 20) and (best is None or m.size < _free[best].size):
                 best = i
         if best is not None:
             return _free.pop(best)
     return None
 
 
-def _give_back(size, addr):
-    lib = _lib.load()
+def _give_back(mem):
     with _lock:
-        _free.append((size, addr))
-        total = sum(s for s, _ in _free)
+        _free.append(mem)
+        total = sum(m.size for m in _free)
         drop = []
         while total > POOL_BYTES and _free:      # oldest first
-            s, a = _free.pop(0)
-            total -= s
-            drop.append(a)
-    for a in drop:
-        lib.gsss_free_host(C.c_void_p(a))
+            m = _free.pop(0)
+            total -= m.size
+            drop.append(m)
+    for m in drop:
+        m.release()
 
 
 def trim():
     """Give every cached block back to the system."""
-    lib = _lib.load()
     with _lock:
-        drop = [a for _, a in _free]
+        drop = list(_free)
         _free.clear()
-    for a in drop:
-        lib.gsss_free_host(C.c_void_p(a))
+    for m in drop:
+        m.release()
 
 
 class _Block:
-    """Owner of one page-locked allocation; numpy arrays made from it keep it alive through `.base`."""
+    """Owner of one page-locked region while an array made from it is alive; numpy arrays keep it alive through `.base`."""
 
     def __init__(self, nbytes, device):
-        got = _take(nbytes)
-        if got is None:
-            p = C.c_void_p()
-            _lib.check(_lib.load().gsss_malloc_host(C.byref(p), max(1, nbytes), device))
-            got = (max(1, nbytes), p.value)
-        self.size, self.addr = got
+        self.mem = _take(nbytes) or _Memory(nbytes, device)
         self.nbytes = nbytes
 
     def array(self, shape):
-        self.__array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f8", "data": (self.addr, False), "version": 3}
+        self.__array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f8", "data": (self.mem.addr, False), "version": 3}
         return np.asarray(self)
 
     def __del__(self):
-        addr, self.addr = getattr(self, "addr", None), None
-        if addr:
+        mem, self.mem = getattr(self, "mem", None), None
+        if mem is not None:
             try:
-                _give_back(self.size, addr)
+                _give_back(mem)
             except Exception:  # interpreter shutdown
                 pass
 

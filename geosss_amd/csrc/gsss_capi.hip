@@ -944,6 +944,25 @@ int gsss_free_host(void *p_host)
     return GSSS_OK;
 }
 
+int gsss_host_register(void *p_host, size_t bytes, int device)
+{
+    if (!p_host || bytes == 0) {
+        set_error("bad argument to gsss_host_register");
+        return GSSS_E_INVALID;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return GSSS_E_HIP;
+    GSSS_HIP_TRY(hipHostRegister(p_host, bytes, hipHostRegisterDefault));
+    return GSSS_OK;
+}
+
+int gsss_host_unregister(void *p_host)
+{
+    if (!p_host) return GSSS_OK;
+    GSSS_HIP_TRY(hipHostUnregister(p_host));
+    return GSSS_OK;
+}
+
 int gsss_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream)
 {
     DeviceGuard guard(device);

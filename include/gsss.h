@@ -328,6 +328,11 @@ int gsss_memset(void *dst_dev, int value, size_t bytes, int device, void *stream
  * overlaps the kernel of the next (geosss_amd/mcmc.py sample).  The buffer must stay alive until the stream has drained. */
 int gsss_malloc_host(void **out_host, size_t bytes, int device);
 int gsss_free_host(void *p_host);
+/* ... or the caller's own pages, page-locked where they lie (hipHostRegister): locking pages that were TOUCHED before costs 4 ms for
+ * 2.4 GB, locking untouched ones 105 ms -- the page faults, taken one by one inside the call (gsss_malloc_host: 107 ms); a host with
+ * several cores touches them in parallel first (11 ms on 16 threads; tools/microbench_pinning.py, geosss_amd/_pinned.py). */
+int gsss_host_register(void *p_host, size_t bytes, int device);
+int gsss_host_unregister(void *p_host);
 int gsss_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, int device, void *stream);
 int gsss_stream_synchronize(int device, void *stream);
 
