@@ -233,14 +233,17 @@ def cpu_baseline(gs, workload, d, budget_s=12.0):
     orc.run(tgt, x0, 10, seed=3521, keep_samples=False, n_threads=cores)
     rate = len(x0) * 10 / (time.perf_counter() - t0)
     n_chains = 4096 * cores
-    n_steps = int(max(50, budget_s * rate / n_chains))
+    n_steps = int(max(50, 0.5 * budget_s * rate / n_chains))
     x0 = orc.sample_sphere(0, n_chains, d)
-    t0 = time.perf_counter()
-    out = orc.run(tgt, x0, n_steps, seed=3521, keep_samples=False, n_threads=cores)
-    dt = time.perf_counter() - t0
+    dts = []
+    for rep in range(2):  # two samples, the better one quoted: the box's cores are shared, and one unlucky reading was 4 x low
+        t0 = time.perf_counter()
+        out = orc.run(tgt, x0, n_steps, seed=3521 + rep, keep_samples=False, n_threads=cores)
+        dts.append(time.perf_counter() - t0)
+    dt = min(dts)
     return {"value": n_chains * n_steps / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n_chains} chains x {n_steps} steps of the same target and sampler, C oracle with OpenMP over "
-                      f"chains on {cores} threads, {dt:.1f} s",
+                      f"chains on {cores} threads, {dt:.1f} s (the better of two samples: {dts[0]:.1f}, {dts[1]:.1f} s)",
             "tries_per_step": float(out["n_tries"].sum() / (n_chains * n_steps)),
             "reference": reference_timing(workload), "numpy_port": numpy_port_baseline(workload, cores)}
 
